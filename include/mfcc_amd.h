@@ -1,0 +1,157 @@
+/*
+ * mfcc_amd.h -- C ABI of the MI355X (gfx950) MFCC front-end.
+ *
+ * The reference (Robomate/mfcc) has no FFI layer: its hot path is thirteen
+ * module-level numpy functions in mfcc-self5.py / mfcc-self15.py called only by
+ * their own main().  Each entry point below therefore cites the reference
+ * FUNCTION it replaces (file:line into /root/reference); the ctypes binding a
+ * maintainer adds is shown in INTEGRATION.md and shipped as mfcc_amd/_capi.py.
+ *
+ * Conventions
+ *   - every function returns MFCC_OK (0) or a negative MFCC_ERR_* code; the
+ *     text of the last error on the calling thread is mfcc_last_error();
+ *   - pointers are DEVICE pointers unless the parameter name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     device work is enqueued on it and the call returns without waiting;
+ *   - a plan / layout belongs to the device it was created on; the caller
+ *     keeps that device current while using it;
+ *   - no call allocates device memory except the *_create functions.
+ */
+#ifndef MFCC_AMD_H
+#define MFCC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFCC_OK 0
+#define MFCC_ERR_INVALID (-1)     /* bad argument                                   */
+#define MFCC_ERR_UNSUPPORTED (-2) /* configuration outside what the kernels cover   */
+#define MFCC_ERR_HIP (-3)         /* a HIP runtime call failed                      */
+#define MFCC_ERR_NOMEM (-4)       /* host or device allocation failed               */
+
+/* audio sample types (mfcc-self5.py:32-36 loadrawdata -> int16; wav.read :196) */
+#define MFCC_AUDIO_I16 0
+#define MFCC_AUDIO_F32 1
+
+/* which spectrum feeds the mel bank: mfcc-self5.py:217 (power) / mfcc-self15.py:234 (magnitude) */
+#define MFCC_SPECTRUM_POWER 0
+#define MFCC_SPECTRUM_MAG 1
+
+/* mfcc-self5.py:78,95: np.hamming is computed but NOT applied -> NONE is the reference behaviour */
+#define MFCC_WINDOW_NONE 0
+#define MFCC_WINDOW_HAMMING 1
+
+/* what mfcc_forward writes, one row per frame */
+#define MFCC_OUT_MFCC39 0  /* [F, 3*numcep]  c | delta | delta-delta   (mfcc-self5.py:181-186) */
+#define MFCC_OUT_STATIC 1  /* [F, numcep]    c0 := ln E               (mfcc-self5.py:158-167) */
+#define MFCC_OUT_LOGMEL 2  /* [F, num_bins+1] ln mel | ln E           (mfcc-self5.py:119-134) */
+#define MFCC_OUT_SPEC 3    /* [F, nfft/2+1]  |X|^2/nfft or |X|        (mfcc-self5.py:96-99)  */
+#define MFCC_OUT_LOGSPEC 4 /* [F, nfft/2+1]  natural log of the above                        */
+
+/* Mirrors the reference's module-level globals (mfcc-self5.py:21-29) and the
+ * keyword defaults of its functions.  mfcc_config_default() fills the values of
+ * mfcc-self5.py's main(). */
+typedef struct mfcc_config {
+  double fs;          /* 16000            mfcc-self5.py:28                      */
+  double frame_time;  /* 25 (ms)          mfcc-self5.py:21, winfft :70,75       */
+  double step_time;   /* 10 (ms)          mfcc-self5.py:22, winfft :70,76       */
+  int32_t num_bins;   /* 26               mfcc-self5.py:23, melbanks :102       */
+  double low_freq;    /* 0                mfcc-self5.py:24, melbanks :105       */
+  int32_t numcep;     /* 13               mfcc-self5.py:219 (staticfeatures hard-codes 13, :161) */
+  double lift_factor; /* 22; <=0 = off    mfcc-self5.py:26, dctopt :144-156     */
+  int32_t pad_fac;    /* 2                delta :169                            */
+  int32_t use_preemph;/* 1 (self5) / 0 (self15, mfcc-self15.py:230)             */
+  double preemph;     /* 0.97             preemphasis :66                       */
+  int32_t spectrum;   /* MFCC_SPECTRUM_*                                        */
+  int32_t window;     /* MFCC_WINDOW_*                                          */
+  int32_t floor_mel;  /* 0 = ln of the unfloored mel sum, -inf on silence (mfcc-self5.py:126-127);
+                         1 = floor exact zeros to float64 eps first            */
+} mfcc_config;
+
+typedef struct mfcc_plan mfcc_plan;     /* immutable constant tables on one device          */
+typedef struct mfcc_layout mfcc_layout; /* geometry of one ragged batch (offsets, tile list) */
+typedef struct mfcc_stream mfcc_stream; /* state of a batch of live audio streams           */
+
+/* ---- library ------------------------------------------------------------- */
+int mfcc_version(void);
+const char* mfcc_last_error(void);
+void mfcc_config_default(mfcc_config* cfg); /* = mfcc-self5.py main(), :211-229 */
+
+/* ---- host-side constants (double precision, no device needed) -------------- */
+/* melbanks(fs, numbins, lowfreq, num_fft) -> [numbins, num_fft/2+1] row-major.  mfcc-self5.py:102-117 */
+int mfcc_melbank_host(double fs, int32_t numbins, double lowfreq, int32_t num_fft, double* out_host);
+/* frame_size, frame_step, num_fft exactly as winfft derives them.  mfcc-self5.py:75-84 */
+int mfcc_frame_geometry(double fs, double frame_time, double step_time, int32_t* frame_size, int32_t* frame_step,
+                        int32_t* num_fft);
+/* pos+1 of winfft's padding loop.  mfcc-self5.py:85-92 */
+int64_t mfcc_frames_for_length(int64_t n_samples, int32_t frame_size, int32_t frame_step);
+
+/* ---- plan ---------------------------------------------------------------- */
+int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out);
+int mfcc_plan_destroy(mfcc_plan* plan);
+int mfcc_plan_info(const mfcc_plan* plan, int32_t* frame_size, int32_t* frame_step, int32_t* num_fft,
+                   int32_t* num_bins, int32_t* numcep);
+
+/* ---- batch layout ---------------------------------------------------------- */
+/* n_utts utterances stored back to back: utterance u occupies samples
+ * [sample_offset[u], sample_offset[u+1]) of `audio` and rows
+ * [frame_offset[u], frame_offset[u+1]) of `out`.  The reference processes one
+ * utterance per main() call (mfcc-self5.py:188-229); every per-utterance rule
+ * (y[0]=x[0], tail zero padding, delta edge replication) is applied per entry. */
+int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64_t n_utts, mfcc_layout** out);
+int mfcc_layout_destroy(mfcc_layout* layout);
+int mfcc_layout_info(const mfcc_layout* layout, int64_t* n_utts, int64_t* total_samples, int64_t* total_frames);
+/* copies the (n_utts+1) prefix sums to host arrays; either pointer may be NULL */
+int mfcc_layout_offsets_host(const mfcc_layout* layout, int64_t* sample_offsets_host, int64_t* frame_offsets_host);
+
+/* ---- the fused hot path ------------------------------------------------------
+ * audio -> pre-emphasis -> framing -> rFFT -> spectrum -> mel -> ln -> DCT -> lifter
+ *       -> c0:=lnE -> delta -> delta-delta -> out rows.
+ * Replaces main()'s call chain mfcc-self5.py:211-229 (mfcc-self15.py:228-246).
+ * `out` has `out_ld` floats per row (>= the row width of out_kind). */
+int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype,
+                 float* out, int64_t out_ld, int32_t out_kind, void* stream);
+int32_t mfcc_out_width(const mfcc_plan* plan, int32_t out_kind);
+
+/* ---- the reference's stages one at a time (float32 device arrays) ------------- */
+/* preemphasis(signal, coeff).  mfcc-self5.py:66-68 */
+int mfcc_preemphasis(const void* signal, int32_t dtype, int64_t n, double coeff, float* out, void* stream);
+/* melspec(spec_list, melbank): ln(spec @ melbank^T) [F,nmel] and floored ln(sum spec) [F].  mfcc-self5.py:119-134 */
+int mfcc_melspec(const float* spec, int64_t n_frames, int32_t n_bins, const float* melbank, int32_t nmel,
+                 int32_t floor_mel, float* logmel, float* loge, void* stream);
+/* mfcc(melspec_list, numcep): DCT-II 'ortho', first numcep.  mfcc-self5.py:136-142 */
+int mfcc_dct(const float* logmel, int64_t n_frames, int32_t nmel, int32_t numcep, float* out, void* stream);
+/* dctopt(mfcc_list, lift_factor).  mfcc-self5.py:144-156 */
+int mfcc_lifter(const float* cep, int64_t n_frames, int32_t ncoeff, double lift_factor, float* out, void* stream);
+/* delta(features, pad_fac) over ONE utterance of n_frames rows.  mfcc-self5.py:169-179 */
+int mfcc_delta(const float* feats, int64_t n_frames, int32_t ncol, int32_t pad_fac, float* out, void* stream);
+/* strided column copy dst[r, 0:ncol] = src[r, 0:ncol] -- staticfeatures' c0 overwrite (:164) and
+ * spectrograms' concatenation (:184-185) are built from it */
+int mfcc_copy_cols(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t n_rows, int32_t ncol,
+                   void* stream);
+
+/* ---- context stacking ----------------------------------------------------------
+ * padUtterance + slidingWin, MLP_5hidlayer_40.py:70-105:
+ * out[t, f*C + c] = feats[clamp(t + f - (N-1)/2, 0, F_u-1), c] per utterance of the
+ * layout (frame-major; N = framenum).  feats is [total_frames, C] with row stride feats_ld. */
+int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t feats_ld, int32_t ncol,
+                       int32_t framenum, float* out, void* stream);
+
+/* ---- CMVN ---------------------------------------------------------------------------
+ * sums[0] += n_rows, sums[1..D] += sum_x, sums[1+D..2D] += sum_x^2 (float64, device).
+ * Generalises the per-utterance (x-mean)/std of inference_ctc_eri_05.py:291 and the
+ * corpus constants (x+mm).*vv of anal_recog_nn_liste.m:180.  The caller zeroes `sums`
+ * and all-reduces it across ranks. */
+int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums,
+                         void* stream);
+/* feats[r,c] = (feats[r,c] + mm[c]) * vv[c] in place; mm, vv are float32[ncol] on the device */
+int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, const float* mm, const float* vv,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFCC_AMD_H */

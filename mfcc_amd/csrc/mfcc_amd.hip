@@ -1,0 +1,453 @@
+// C ABI of the MI355X MFCC front-end (see include/mfcc_amd.h).
+#include "../../include/mfcc_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fused_kernel.h"
+#include "stage_kernels.h"
+#include "tables.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(MFCC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+int upload(const std::vector<T>& host, T** dev) {
+  *dev = nullptr;
+  if (host.empty()) return MFCC_OK;
+  HIP_TRY(hipMalloc((void**)dev, host.size() * sizeof(T)));
+  HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  return MFCC_OK;
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+struct mfcc_plan {
+  mfcc_config cfg;
+  int device;
+  int32_t frame_size, frame_step, nfft;
+  float* tw512 = nullptr;
+  float* melw = nullptr;
+  int2* melrange = nullptr;
+  float* dctw = nullptr;
+  float* window = nullptr;
+  float pre_hi, pre_lo, spec_scale;
+};
+
+struct mfcc_layout {
+  int device;
+  int64_t n_utts, total_samples, total_frames;
+  std::vector<int64_t> sample_off, frame_off;
+  int64_t* d_sample_off = nullptr;
+  int64_t* d_frame_off = nullptr;
+  mfcc::Tile* d_tiles = nullptr;
+  int32_t* d_row_utt = nullptr;
+  int64_t n_tiles;
+};
+
+extern "C" {
+
+int mfcc_version(void) { return 100; }
+
+const char* mfcc_last_error(void) { return g_err; }
+
+void mfcc_config_default(mfcc_config* cfg) {
+  if (!cfg) return;
+  cfg->fs = 16000;
+  cfg->frame_time = 25;
+  cfg->step_time = 10;
+  cfg->num_bins = 26;
+  cfg->low_freq = 0;
+  cfg->numcep = 13;
+  cfg->lift_factor = 22;
+  cfg->pad_fac = 2;
+  cfg->use_preemph = 1;
+  cfg->preemph = 0.97;
+  cfg->spectrum = MFCC_SPECTRUM_POWER;
+  cfg->window = MFCC_WINDOW_NONE;
+  cfg->floor_mel = 0;
+}
+
+int mfcc_melbank_host(double fs, int32_t numbins, double lowfreq, int32_t num_fft, double* out_host) {
+  if (!out_host || numbins < 1 || num_fft < 2 || fs <= 0) return fail(MFCC_ERR_INVALID, "mfcc_melbank_host: bad argument");
+  const std::vector<double> b = mfcc::melbank(fs, numbins, lowfreq, num_fft);
+  memcpy(out_host, b.data(), b.size() * sizeof(double));
+  return MFCC_OK;
+}
+
+int mfcc_frame_geometry(double fs, double frame_time, double step_time, int32_t* frame_size, int32_t* frame_step,
+                        int32_t* num_fft) {
+  if (!frame_size || !frame_step || !num_fft) return fail(MFCC_ERR_INVALID, "mfcc_frame_geometry: null output");
+  mfcc::frame_geometry(fs, frame_time, step_time, frame_size, frame_step, num_fft);
+  return MFCC_OK;
+}
+
+int64_t mfcc_frames_for_length(int64_t n_samples, int32_t frame_size, int32_t frame_step) {
+  if (n_samples < 0 || frame_size < 1 || frame_step < 1) return fail(MFCC_ERR_INVALID, "mfcc_frames_for_length: bad argument");
+  return mfcc::frames_for_length(n_samples, frame_size, frame_step);
+}
+
+int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
+  if (!cfg || !out) return fail(MFCC_ERR_INVALID, "mfcc_plan_create: null argument");
+  *out = nullptr;
+  int32_t size, step, nfft;
+  mfcc::frame_geometry(cfg->fs, cfg->frame_time, cfg->step_time, &size, &step, &nfft);
+  if (size != mfcc::kFrameSize || step != mfcc::kFrameStep || nfft != mfcc::kNfft)
+    return fail(MFCC_ERR_UNSUPPORTED,
+                "framing %d/%d samples, %d-point FFT: the gfx950 kernels are built for 400/160/512 "
+                "(fs=16000, 25 ms / 10 ms)", size, step, nfft);
+  if (cfg->num_bins < 1 || cfg->num_bins > mfcc::kMaxMel)
+    return fail(MFCC_ERR_UNSUPPORTED, "num_bins=%d outside 1..%d", cfg->num_bins, mfcc::kMaxMel);
+  if (cfg->numcep < 1 || cfg->numcep > mfcc::kMaxCep || cfg->numcep > cfg->num_bins)
+    return fail(MFCC_ERR_UNSUPPORTED, "numcep=%d outside 1..min(%d, num_bins)", cfg->numcep, mfcc::kMaxCep);
+  if (cfg->pad_fac != 2) return fail(MFCC_ERR_UNSUPPORTED, "pad_fac=%d: the fused kernel implements pad_fac=2", cfg->pad_fac);
+  if (cfg->spectrum != MFCC_SPECTRUM_POWER && cfg->spectrum != MFCC_SPECTRUM_MAG)
+    return fail(MFCC_ERR_INVALID, "spectrum=%d", cfg->spectrum);
+  if (cfg->window != MFCC_WINDOW_NONE && cfg->window != MFCC_WINDOW_HAMMING)
+    return fail(MFCC_ERR_INVALID, "window=%d", cfg->window);
+  if (cfg->low_freq < 0 || cfg->low_freq >= cfg->fs / 2) return fail(MFCC_ERR_INVALID, "low_freq=%g", cfg->low_freq);
+
+  HIP_TRY(hipSetDevice(device));
+  mfcc_plan* p = new (std::nothrow) mfcc_plan();
+  if (!p) return fail(MFCC_ERR_NOMEM, "mfcc_plan_create: out of host memory");
+  p->cfg = *cfg;
+  p->device = device;
+  p->frame_size = size;
+  p->frame_step = step;
+  p->nfft = nfft;
+  p->pre_hi = (float)cfg->preemph;
+  p->pre_lo = (float)(cfg->preemph - (double)p->pre_hi);
+  // spectrum rows in LDS hold 4|X|^2 (power) or 2|X| (magnitude); both scales are powers of two
+  p->spec_scale = cfg->spectrum == MFCC_SPECTRUM_POWER ? 1.0f / (4.0f * nfft) : 0.5f;
+
+  const int nmel = cfg->num_bins;
+  const std::vector<double> bank = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft);
+  std::vector<float> melw((size_t)nmel * mfcc::kMelLd, 0.f);
+  std::vector<int2> range(nmel);
+  for (int j = 0; j < nmel; ++j) {
+    int first = -1, last = -1;
+    for (int k = 0; k < mfcc::kNbin; ++k) {
+      const double w = bank[(size_t)j * mfcc::kNbin + k];
+      melw[(size_t)j * mfcc::kMelLd + k] = (float)(w * (double)p->spec_scale);
+      if (w != 0.0) { if (first < 0) first = k; last = k; }
+    }
+    range[j] = first < 0 ? make_int2(0, 0) : make_int2(first, last - first + 1);
+  }
+  const std::vector<double> dl = mfcc::dct_lifter(nmel, cfg->numcep, cfg->lift_factor, true);
+  std::vector<float> dctw((size_t)nmel * mfcc::kMaxCep, 0.f);
+  for (int j = 0; j < nmel; ++j)
+    for (int c = 0; c < cfg->numcep; ++c) dctw[(size_t)j * mfcc::kMaxCep + c] = (float)dl[(size_t)j * cfg->numcep + c];
+  std::vector<float> win;
+  if (cfg->window == MFCC_WINDOW_HAMMING) {
+    const std::vector<double> h = mfcc::hamming(size);
+    win.assign(512, 0.f);
+    for (int n = 0; n < size; ++n) win[n] = (float)h[n];
+  }
+  int rc;
+  if ((rc = upload(mfcc::twiddle512(), &p->tw512)) || (rc = upload(melw, &p->melw)) ||
+      (rc = upload(range, &p->melrange)) || (rc = upload(dctw, &p->dctw)) || (rc = upload(win, &p->window))) {
+    mfcc_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return MFCC_OK;
+}
+
+int mfcc_plan_destroy(mfcc_plan* p) {
+  if (!p) return MFCC_OK;
+  (void)hipFree(p->tw512);
+  (void)hipFree(p->melw);
+  (void)hipFree(p->melrange);
+  (void)hipFree(p->dctw);
+  (void)hipFree(p->window);
+  delete p;
+  return MFCC_OK;
+}
+
+int mfcc_plan_info(const mfcc_plan* p, int32_t* frame_size, int32_t* frame_step, int32_t* num_fft, int32_t* num_bins,
+                   int32_t* numcep) {
+  if (!p) return fail(MFCC_ERR_INVALID, "mfcc_plan_info: null plan");
+  if (frame_size) *frame_size = p->frame_size;
+  if (frame_step) *frame_step = p->frame_step;
+  if (num_fft) *num_fft = p->nfft;
+  if (num_bins) *num_bins = p->cfg.num_bins;
+  if (numcep) *numcep = p->cfg.numcep;
+  return MFCC_OK;
+}
+
+int32_t mfcc_out_width(const mfcc_plan* p, int32_t out_kind) {
+  if (!p) return fail(MFCC_ERR_INVALID, "mfcc_out_width: null plan");
+  switch (out_kind) {
+    case MFCC_OUT_MFCC39: return 3 * p->cfg.numcep;
+    case MFCC_OUT_STATIC: return p->cfg.numcep;
+    case MFCC_OUT_LOGMEL: return p->cfg.num_bins + 1;
+    case MFCC_OUT_SPEC:
+    case MFCC_OUT_LOGSPEC: return p->nfft / 2 + 1;
+  }
+  return fail(MFCC_ERR_INVALID, "out_kind=%d", out_kind);
+}
+
+int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64_t n_utts, mfcc_layout** out) {
+  if (!plan || !out || n_utts < 0 || (n_utts > 0 && !lengths_host)) return fail(MFCC_ERR_INVALID, "mfcc_layout_create: bad argument");
+  if (n_utts > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "more than 2^31-1 utterances in one layout");
+  *out = nullptr;
+  mfcc_layout* l = new (std::nothrow) mfcc_layout();
+  if (!l) return fail(MFCC_ERR_NOMEM, "mfcc_layout_create: out of host memory");
+  l->device = plan->device;
+  l->n_utts = n_utts;
+  l->sample_off.assign(n_utts + 1, 0);
+  l->frame_off.assign(n_utts + 1, 0);
+  std::vector<mfcc::Tile> tiles;
+  for (int64_t u = 0; u < n_utts; ++u) {
+    const int64_t len = lengths_host[u];
+    if (len < 1) {
+      delete l;
+      return fail(MFCC_ERR_INVALID, "utterance %lld has length %lld (the reference needs >= 1 sample: signal[0], mfcc-self5.py:68)",
+                  (long long)u, (long long)len);
+    }
+    const int64_t nf = mfcc::frames_for_length(len, plan->frame_size, plan->frame_step);
+    if (nf > INT32_MAX) {
+      delete l;
+      return fail(MFCC_ERR_UNSUPPORTED, "utterance %lld has more than 2^31-1 frames", (long long)u);
+    }
+    l->sample_off[u + 1] = l->sample_off[u] + len;
+    l->frame_off[u + 1] = l->frame_off[u] + nf;
+    const int64_t ntile = (nf + mfcc::kTileFrames - 1) / mfcc::kTileFrames;
+    for (int64_t i = 0; i < ntile; ++i) {
+      const int64_t a = i * nf / ntile, b = (i + 1) * nf / ntile;
+      tiles.push_back(mfcc::Tile{(int32_t)u, (int32_t)a, (int32_t)(b - a), 0});
+    }
+  }
+  l->total_samples = l->sample_off[n_utts];
+  l->total_frames = l->frame_off[n_utts];
+  l->n_tiles = (int64_t)tiles.size();
+  if (l->n_tiles > INT32_MAX) {
+    delete l;
+    return fail(MFCC_ERR_UNSUPPORTED, "layout needs more than 2^31-1 workgroups; split the batch");
+  }
+  std::vector<int32_t> row_utt((size_t)l->total_frames);
+  for (int64_t u = 0; u < n_utts; ++u)
+    for (int64_t r = l->frame_off[u]; r < l->frame_off[u + 1]; ++r) row_utt[(size_t)r] = (int32_t)u;
+  hipError_t e = hipSetDevice(plan->device);
+  int rc = e == hipSuccess ? MFCC_OK : fail(MFCC_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  if (!rc) rc = upload(l->sample_off, &l->d_sample_off);
+  if (!rc) rc = upload(l->frame_off, &l->d_frame_off);
+  if (!rc) rc = upload(tiles, &l->d_tiles);
+  if (!rc) rc = upload(row_utt, &l->d_row_utt);
+  if (rc) {
+    mfcc_layout_destroy(l);
+    return rc;
+  }
+  *out = l;
+  return MFCC_OK;
+}
+
+int mfcc_layout_destroy(mfcc_layout* l) {
+  if (!l) return MFCC_OK;
+  (void)hipFree(l->d_sample_off);
+  (void)hipFree(l->d_frame_off);
+  (void)hipFree(l->d_tiles);
+  (void)hipFree(l->d_row_utt);
+  delete l;
+  return MFCC_OK;
+}
+
+int mfcc_layout_info(const mfcc_layout* l, int64_t* n_utts, int64_t* total_samples, int64_t* total_frames) {
+  if (!l) return fail(MFCC_ERR_INVALID, "mfcc_layout_info: null layout");
+  if (n_utts) *n_utts = l->n_utts;
+  if (total_samples) *total_samples = l->total_samples;
+  if (total_frames) *total_frames = l->total_frames;
+  return MFCC_OK;
+}
+
+int mfcc_layout_offsets_host(const mfcc_layout* l, int64_t* sample_offsets_host, int64_t* frame_offsets_host) {
+  if (!l) return fail(MFCC_ERR_INVALID, "mfcc_layout_offsets_host: null layout");
+  if (sample_offsets_host) memcpy(sample_offsets_host, l->sample_off.data(), l->sample_off.size() * sizeof(int64_t));
+  if (frame_offsets_host) memcpy(frame_offsets_host, l->frame_off.data(), l->frame_off.size() * sizeof(int64_t));
+  return MFCC_OK;
+}
+
+int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype, float* out,
+                 int64_t out_ld, int32_t out_kind, void* stream) {
+  if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward: null plan or layout");
+  if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
+  if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
+  const int32_t width = mfcc_out_width(plan, out_kind);
+  if (width < 0) return width;
+  if (out_ld < width) return fail(MFCC_ERR_INVALID, "out_ld=%lld < row width %d", (long long)out_ld, width);
+  if (layout->n_utts == 0) return MFCC_OK;
+  if (!audio || !out) return fail(MFCC_ERR_INVALID, "mfcc_forward: null device pointer");
+
+  mfcc::FusedParams fp;
+  fp.audio = audio;
+  fp.sample_off = layout->d_sample_off;
+  fp.frame_off = layout->d_frame_off;
+  fp.tiles = layout->d_tiles;
+  fp.out = out;
+  fp.out_ld = out_ld;
+  fp.tw512 = plan->tw512;
+  fp.melw = plan->melw;
+  fp.melrange = plan->melrange;
+  fp.dctw = plan->dctw;
+  fp.window = plan->window;
+  fp.nmel = plan->cfg.num_bins;
+  fp.numcep = plan->cfg.numcep;
+  fp.audio_dtype = audio_dtype;
+  fp.use_preemph = plan->cfg.use_preemph;
+  fp.pre_hi = plan->pre_hi;
+  fp.pre_lo = plan->pre_lo;
+  fp.spectrum = plan->cfg.spectrum;
+  fp.floor_mel = plan->cfg.floor_mel;
+  fp.spec_scale = plan->spec_scale;
+
+  const dim3 grid((unsigned)layout->n_tiles), block(256);
+  const size_t smem = mfcc::kSmemFloats * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  switch (out_kind) {
+    case MFCC_OUT_MFCC39: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutMfcc39>, grid, block, smem, st, fp); break;
+    case MFCC_OUT_STATIC: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutStatic>, grid, block, smem, st, fp); break;
+    case MFCC_OUT_LOGMEL: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutLogmel>, grid, block, smem, st, fp); break;
+    case MFCC_OUT_SPEC: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutSpec>, grid, block, smem, st, fp); break;
+    case MFCC_OUT_LOGSPEC: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutLogspec>, grid, block, smem, st, fp); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_preemphasis(const void* signal, int32_t dtype, int64_t n, double coeff, float* out, void* stream) {
+  if (n < 0 || (n > 0 && (!signal || !out))) return fail(MFCC_ERR_INVALID, "mfcc_preemphasis: bad argument");
+  if (n == 0) return MFCC_OK;
+  const float hi = (float)coeff, lo = (float)(coeff - (double)hi);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MFCC_AUDIO_I16)
+    hipLaunchKernelGGL(mfcc::preemph_kernel<int16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const int16_t*)signal, n, hi, lo, out);
+  else if (dtype == MFCC_AUDIO_F32)
+    hipLaunchKernelGGL(mfcc::preemph_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const float*)signal, n, hi, lo, out);
+  else
+    return fail(MFCC_ERR_INVALID, "dtype=%d", dtype);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_melspec(const float* spec, int64_t n_frames, int32_t n_bins, const float* melbank, int32_t nmel, int32_t floor_mel,
+                 float* logmel, float* loge, void* stream) {
+  if (n_frames < 0 || n_bins < 1 || nmel < 1) return fail(MFCC_ERR_INVALID, "mfcc_melspec: bad shape");
+  if (n_frames == 0) return MFCC_OK;
+  if (!spec || !melbank || !logmel || !loge) return fail(MFCC_ERR_INVALID, "mfcc_melspec: null pointer");
+  if (n_frames > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_melspec: more than 2^31-1 frames per call");
+  hipLaunchKernelGGL(mfcc::melspec_kernel, dim3((unsigned)n_frames), dim3(64), 0, (hipStream_t)stream, spec, n_bins, melbank, nmel,
+                     floor_mel, logmel, loge);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_dct(const float* logmel, int64_t n_frames, int32_t nmel, int32_t numcep, float* out, void* stream) {
+  if (n_frames < 0 || nmel < 1 || numcep < 1 || numcep > nmel) return fail(MFCC_ERR_INVALID, "mfcc_dct: bad shape");
+  if (n_frames == 0) return MFCC_OK;
+  if (!logmel || !out) return fail(MFCC_ERR_INVALID, "mfcc_dct: null pointer");
+  const int64_t total = n_frames * numcep;
+  hipLaunchKernelGGL(mfcc::dct_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logmel, n_frames, nmel, numcep, out);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_lifter(const float* cep, int64_t n_frames, int32_t ncoeff, double lift_factor, float* out, void* stream) {
+  if (n_frames < 0 || ncoeff < 1) return fail(MFCC_ERR_INVALID, "mfcc_lifter: bad shape");
+  if (n_frames == 0) return MFCC_OK;
+  if (!cep || !out) return fail(MFCC_ERR_INVALID, "mfcc_lifter: null pointer");
+  const int64_t total = n_frames * ncoeff;
+  hipLaunchKernelGGL(mfcc::lifter_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, cep, n_frames, ncoeff,
+                     lift_factor, out);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_delta(const float* feats, int64_t n_frames, int32_t ncol, int32_t pad_fac, float* out, void* stream) {
+  if (n_frames < 0 || ncol < 1 || pad_fac < 1) return fail(MFCC_ERR_INVALID, "mfcc_delta: bad shape");
+  if (n_frames == 0) return MFCC_OK;
+  if (!feats || !out) return fail(MFCC_ERR_INVALID, "mfcc_delta: null pointer");
+  int denom = 0;
+  for (int i = 1; i <= pad_fac; ++i) denom += 2 * i * i;  // mfcc-self5.py:172
+  const int64_t total = n_frames * ncol;
+  hipLaunchKernelGGL(mfcc::delta_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, feats, n_frames, ncol, pad_fac,
+                     1.0f / (float)denom, out);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_copy_cols(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t n_rows, int32_t ncol, void* stream) {
+  if (n_rows < 0 || ncol < 1 || src_ld < ncol || dst_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_copy_cols: bad shape");
+  if (n_rows == 0) return MFCC_OK;
+  if (!src || !dst) return fail(MFCC_ERR_INVALID, "mfcc_copy_cols: null pointer");
+  const int64_t total = n_rows * ncol;
+  hipLaunchKernelGGL(mfcc::copy_cols_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, src_ld, dst, dst_ld,
+                     n_rows, ncol);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t feats_ld, int32_t ncol, int32_t framenum, float* out,
+                       void* stream) {
+  if (!layout) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: null layout");
+  if (ncol < 1 || feats_ld < ncol || framenum < 1) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: bad shape");
+  if (framenum % 2 == 0)
+    return fail(MFCC_ERR_INVALID, "framenum=%d: use an odd number of frames (MLP_5hidlayer_40.py:261-262 warns the same)", framenum);
+  if (layout->total_frames == 0) return MFCC_OK;
+  if (!feats || !out) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: null pointer");
+  if (layout->total_frames > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_stack_context: more than 2^31-1 rows per call");
+  hipLaunchKernelGGL(mfcc::stack_context_kernel, dim3((unsigned)layout->total_frames), dim3(256), 0, (hipStream_t)stream, feats, feats_ld,
+                     ncol, framenum, layout->d_frame_off, layout->d_row_utt, out);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums, void* stream) {
+  if (n_rows < 0 || ncol < 1 || ncol > 1024 || feats_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate: bad shape");
+  if (n_rows == 0) return MFCC_OK;
+  if (!feats || !sums) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate: null pointer");
+  int threads = 256;
+  while (threads < ncol) threads += 64;
+  const int64_t rows_per_block = 512;
+  const int64_t nblk = (n_rows + rows_per_block - 1) / rows_per_block;
+  if (nblk > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_cmvn_accumulate: too many rows per call");
+  hipLaunchKernelGGL(mfcc::cmvn_accumulate_kernel, dim3((unsigned)nblk), dim3(threads), 2 * threads * sizeof(double), (hipStream_t)stream,
+                     feats, feats_ld, n_rows, ncol, rows_per_block, sums);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, const float* mm, const float* vv, void* stream) {
+  if (n_rows < 0 || ncol < 1 || feats_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_apply: bad shape");
+  if (n_rows == 0) return MFCC_OK;
+  if (!feats || !mm || !vv) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_apply: null pointer");
+  const int64_t total = n_rows * ncol;
+  hipLaunchKernelGGL(mfcc::cmvn_apply_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, feats, feats_ld, n_rows, ncol,
+                     mm, vv);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors produced by
+the reference's own functions and against the CPU oracle on seeded inputs.
+
+Tolerances (float32 kernels vs the float64 reference):
+  * ln-mel / ln-energy: 1e-4 RELATIVE  (|gpu - ref| <= 1e-4 |ref|);
+  * cepstra, delta, delta-delta (all 39 columns): 1e-3 ABSOLUTE;
+  * integer / copy operations (stacking, .pat round trip): bit exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mfcc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOGMEL_RTOL = 1e-4
+CEP_ATOL = 1e-3
+VARIANTS = ("self5", "self15")
+
+
+@pytest.fixture(scope="module")
+def M():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import mfcc_amd
+    return mfcc_amd
+
+
+def assert_logmel(gpu, ref, what):
+    gpu = np.asarray(gpu, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert gpu.shape == ref.shape, what
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(gpu), fin), f"{what}: inf/nan pattern differs"
+    assert np.array_equal(gpu[~fin], ref[~fin]) or np.array_equal(np.sign(gpu[~fin]), np.sign(ref[~fin]))
+    rel = np.abs(gpu[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300)
+    assert rel.max(initial=0) <= LOGMEL_RTOL, f"{what}: max rel err {rel.max():.3e} at |ref|={np.abs(ref[fin])[rel.argmax()]:.4g}"
+    return rel.max(initial=0)
+
+
+def assert_cep(gpu, ref, what, atol=CEP_ATOL):
+    gpu = np.asarray(gpu, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert gpu.shape == ref.shape, what
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(gpu), nan), f"{what}: NaN pattern differs"
+    err = np.abs(gpu[~nan] - ref[~nan])
+    assert err.max(initial=0) <= atol, f"{what}: max abs err {err.max():.3e}"
+    return err.max(initial=0)
+
+
+# ----------------------------------------------------------------------------------------
+# the reference's one real utterance, every stage
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_ldc93s1_fused(M, golden, variant):
+    g = golden("ldc93s1.npz")
+    fe = M.MFCC(variant)
+    audio = torch.from_numpy(g["audio"]).cuda()
+    out = fe(audio).cpu().numpy()
+    assert out.shape == (291, 39) and out.dtype == np.float32
+    assert_cep(out, g[f"{variant}_out"], f"{variant} out")
+    lm = fe(audio, kind="logmel").cpu().numpy()
+    assert lm.shape == (291, 27)
+    assert_logmel(lm[:, :26], g[f"{variant}_logmel"], f"{variant} ln-mel")
+    assert_logmel(lm[:, 26], g[f"{variant}_loge"], f"{variant} ln-energy")
+    st = fe(audio, kind="static").cpu().numpy()
+    assert_cep(st, g[f"{variant}_static"], f"{variant} static")
+    rows = g[f"{variant}_rows"]
+    spec = fe(audio, kind="spec").cpu().numpy()
+    ref = g[f"{variant}_pow_rows"] if variant == "self5" else g[f"{variant}_mag_rows"]
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert (np.abs(spec[rows] - ref) <= 2e-6 * scale).all()
+    # numpy input -> numpy output, same numbers
+    out_np = fe(g["audio"])
+    assert isinstance(out_np, np.ndarray) and np.array_equal(out_np, out)
+
+
+def test_ldc93s1_known_answer(M, golden):
+    g = golden("ldc93s1.npz")
+    out = M.mfcc39(g["audio"])
+    assert np.allclose(out[0, :5], [7.07865742, -25.0219473, -6.32589368, -12.31370909, -4.65412786], atol=1e-3)
+    assert abs(float(out.astype(np.float64).sum()) - (-18230.0624550056)) < 0.5
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_synthetic_lengths(M, golden, variant):
+    """Frame-count edge cases (L = 1, 2, 399, 400, 401, 560, 561, 4000, 48000)."""
+    g = golden("synthetic.npz")
+    fe = M.MFCC(variant)
+    for length in g["lengths"]:
+        audio = g[f"audio_{length}"]
+        out = fe(audio)
+        assert out.shape == (O.frame_count(length), 39)
+        assert_cep(out, g[f"{variant}_out_{length}"], f"{variant} L={length}")
+        if length <= 4000:
+            lm = fe(audio, kind="logmel")
+            assert_logmel(lm[:, :26], g[f"{variant}_logmel_{length}"], f"{variant} ln-mel L={length}")
+            assert_logmel(lm[:, 26], g[f"{variant}_loge_{length}"], f"{variant} ln-E L={length}")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_special_inputs(M, golden, variant):
+    """Digital silence (ln 0 = -inf -> NaN cepstra, energy floored at eps), silence after
+    speech, full-scale alternating samples, pure DC."""
+    g = golden("special.npz")
+    fe = M.MFCC(variant)
+    for name in ("zeros", "tailzeros", "fullscale", "dc"):
+        audio = g[f"audio_{name}"]
+        out = fe(audio)
+        ref = g[f"{variant}_out_{name}"]
+        assert_cep(out, ref, f"{variant} {name}")
+        lm = fe(audio, kind="logmel")
+        rl = g[f"{variant}_logmel_{name}"]
+        if name in ("zeros", "tailzeros"):
+            assert np.array_equal(np.isneginf(lm[:, :26]), np.isneginf(rl))
+            fin = np.isfinite(rl)
+            assert np.abs(lm[:, :26][fin] - rl[fin]).max(initial=0) <= 1e-4 * np.maximum(np.abs(rl[fin]), 1).max(initial=1)
+        assert_logmel(lm[:, 26], g[f"{variant}_loge_{name}"], f"{variant} ln-E {name}")
+    z = fe(g["audio_zeros"])
+    assert abs(z[0, 0] - np.log(np.finfo(float).eps)) < 1e-4 and np.isnan(z[:, 1:13]).all()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_float32_input(M, golden, variant):
+    g = golden("float_input.npz")
+    fe = M.MFCC(variant)
+    out = fe(g["audio"])
+    assert_cep(out, g[f"{variant}_out"], f"{variant} float input")
+    lm = fe(g["audio"], kind="logmel")
+    assert_logmel(lm[:, :26], g[f"{variant}_logmel"], f"{variant} float ln-mel")
+
+
+# ----------------------------------------------------------------------------------------
+# batches
+# ----------------------------------------------------------------------------------------
+def test_ragged_batch_equals_single_utterances(M, golden):
+    g = golden("synthetic.npz")
+    lengths = [int(x) for x in g["lengths"]]
+    packed = np.concatenate([g[f"audio_{n}"] for n in lengths])
+    for variant in VARIANTS:
+        fe = M.MFCC(variant)
+        batch = fe(torch.from_numpy(packed).cuda(), lengths=lengths).cpu().numpy()
+        singles = np.concatenate([fe(g[f"audio_{n}"]) for n in lengths])
+        assert np.array_equal(batch, singles, equal_nan=True)
+        ref = np.concatenate([g[f"{variant}_out_{n}"] for n in lengths])
+        assert_cep(batch, ref, f"{variant} ragged batch")
+
+
+def test_long_utterance_tiles_match_oracle(M):
+    """An utterance far longer than one workgroup tile: tile seams must be invisible."""
+    rng = np.random.default_rng(11)
+    audio = np.clip(rng.standard_normal(16000 * 20) * 3000, -32768, 32767).astype(np.int16)
+    for variant in VARIANTS:
+        out = M.MFCC(variant)(audio)
+        ref = O.mfcc39(audio, variant, loop=False)
+        assert_cep(out, ref, f"{variant} 20 s utterance")
+
+
+def test_dense_batch_and_out_argument(M):
+    rng = np.random.default_rng(3)
+    audio = np.clip(rng.standard_normal((7, 8000)) * 3000, -32768, 32767).astype(np.int16)
+    fe = M.MFCC("self5")
+    a = torch.from_numpy(audio).cuda()
+    out = torch.full((7 * 49, 40), -7.0, device="cuda")
+    res = fe(a, out=out)
+    assert res.data_ptr() == out.data_ptr()
+    torch.cuda.synchronize()
+    assert (out[:, 39] == -7.0).all()  # padding column untouched (out_ld = 40)
+    ref = np.concatenate([O.mfcc39(audio[i], "self5", loop=False) for i in range(7)])
+    assert_cep(out[:, :39].cpu().numpy(), ref, "dense batch")
+
+
+def test_full_size_batch_properties(M):
+    """BASELINE config: 10 000 x 3 s.  Checked through size-independent properties: shape,
+    determinism, batch independence (a slice run alone gives the same rows bit for bit),
+    finiteness, and the oracle on a sample of utterances."""
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    audio = (torch.randn(10000, 48000, generator=gen, device="cuda") * 3000).clamp(-32768, 32767).to(torch.int16)
+    fe = M.MFCC("self5")
+    out = fe(audio)
+    assert out.shape == (10000 * 299, 39)
+    out2 = fe(audio)
+    assert torch.equal(out, out2)
+    assert torch.isfinite(out).all()
+    sub = fe(audio[4321:4325].contiguous())
+    assert torch.equal(sub, out[4321 * 299:4325 * 299])
+    for u in (0, 777, 9999):
+        ref = O.mfcc39(audio[u].cpu().numpy(), "self5", loop=False)
+        assert_cep(out[u * 299:(u + 1) * 299].cpu().numpy(), ref, f"utt {u}")
+
+
+# ----------------------------------------------------------------------------------------
+# stage by stage, under the reference's own function names
+# ----------------------------------------------------------------------------------------
+def test_reference_named_stages(M, golden):
+    s = golden("stages.npz")
+    assert_cep(M.preemphasis(s["preemph_in"]), s["preemph_out"], "preemphasis", 2e-3)
+    assert_cep(M.preemphasis(s["preemph_in"], 0.95), s["preemph_out_095"], "preemphasis 0.95", 2e-3)
+    assert_cep(M.delta(s["delta_in"]), s["delta_out"], "delta", 1e-5)
+    assert_cep(M.delta(s["delta_in"], 3), s["delta_out_pad3"], "delta pad 3", 1e-5)
+    assert_cep(M.delta(s["delta_in_1"]), s["delta_out_1"], "delta single frame", 1e-6)
+    assert_cep(M.mfcc(s["dct_in"]), s["dct_out12"], "dct 12", 1e-4)
+    assert_cep(M.mfcc(list(s["dct_in"]), numcep=13), s["dct_out13"], "dct 13", 1e-4)
+    assert_cep(M.dctopt(s["dct_out13"], 22), s["lift_out"], "lifter", 1e-3)
+    assert_cep(M.dctopt(s["dct_out13"], 0), s["lift_out_0"], "lifter off", 1e-5)
+    assert np.array_equal(M.melbanks(16000, 40, 0, 512), s["melbank_40"])
+    assert np.array_equal(M.melbanks(16000, 26, 300, 512), s["melbank_26_low300"])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_reference_main_call_chain(M, golden, variant):
+    """The body of the reference's main() (mfcc-self5.py:211-229 / mfcc-self15.py:228-246)
+    written against this package's names."""
+    g = golden("ldc93s1.npz")
+    audio = g["audio"]
+    fs, frame_time, step_time, num_bins, low_freq, lift_factor = M.fs, M.frame_time, M.step_time, M.num_bins, M.low_freq, M.lift_factor
+    audio_pre = M.preemphasis(audio)
+    magfft_list, powfft_list, win, num_fft = M.winfft(audio_pre if variant == "self5" else audio, fs, frame_time, step_time)
+    melbank = M.melbanks(fs, num_bins, low_freq, num_fft)
+    melspec_list, energy_list = M.melspec(powfft_list if variant == "self5" else magfft_list, melbank)
+    mfcc_list = M.mfcc(melspec_list, numcep=13)
+    mfcclift_list = M.dctopt(mfcc_list, lift_factor)
+    cepstrum = M.staticfeatures(energy_list, mfcclift_list)
+    delta_features = M.delta(cepstrum)
+    delta_delta_features = M.delta(delta_features)
+    spectrogram = M.spectrograms(cepstrum, delta_features, delta_delta_features)
+    assert num_fft == 512 and np.allclose(win, g["win"]) and len(magfft_list) == 291
+    assert sum(1 for _ in powfft_list) == 291 and powfft_list[0].shape == (257,)
+    assert_logmel(melspec_list, g[f"{variant}_logmel"], "stagewise ln-mel")
+    assert_logmel(energy_list, g[f"{variant}_loge"], "stagewise ln-E")
+    assert_cep(spectrogram, g[f"{variant}_out"], "stagewise out")
+    # and the fused path agrees with the staged one
+    assert_cep(M.MFCC(variant)(audio), spectrogram, "fused vs staged", 2e-3)
+
+
+def test_spectrum257_and_hamming_extension(M, golden):
+    g = golden("ldc93s1.npz")
+    audio = g["audio"]
+    pw = M.spectrum257(audio)
+    ref = O.spectrum257(audio, "self5")
+    assert (np.abs(pw - ref) <= 2e-6 * np.abs(ref).max(axis=1, keepdims=True)).all()
+    lg = M.spectrum257(audio, log=True)
+    assert np.abs(lg - np.log(pw)).max() < 1e-5
+    # Hamming-windowed frames (not the reference's behaviour: checked against the oracle's
+    # own window, parity with the reference is not claimed for this mode)
+    sig = O.preemphasis(audio)
+    size, step = 400, 160
+    nfr = O.frame_count(len(audio))
+    padded = np.zeros((nfr - 1) * step + size)
+    padded[:len(sig)] = sig
+    idx = np.arange(nfr)[:, None] * step + np.arange(size)[None, :]
+    refw = np.abs(np.fft.rfft(padded[idx] * np.hamming(size), 512, axis=1)) ** 2 / 512
+    got = M.mfcc39(audio, window="hamming", kind="spec")
+    assert (np.abs(got - refw) <= 2e-6 * refw.max(axis=1, keepdims=True)).all()
+
+
+# ----------------------------------------------------------------------------------------
+# context stacking and the .pat container
+# ----------------------------------------------------------------------------------------
+def test_stacking_bit_exact(M, golden, tmp_path):
+    g = golden("stacking.npz")
+    for name in ("is1c0001_001", "is1c0001_031"):
+        path = tmp_path / f"{name}.pat"
+        path.write_bytes(g[f"{name}_pat_bytes"].tobytes())
+        data = M.loadPatData(str(path), 12)  # [C, F] like the reference
+        assert np.array_equal(data, g[f"{name}_data"])
+        labels = g[f"{name}_labels"]
+        for framenum in (1, 11, 17):
+            ref = g[f"{name}_stack{framenum}"]
+            out = M.stack_context(np.ascontiguousarray(data.T), framenum)
+            assert out.dtype == np.float32 and np.array_equal(out, ref)
+            plab, pdat = M.padUtterance(framenum, labels, data)
+            assert pdat.shape == (39, data.shape[1] + framenum - 1)
+            lablist, veclist = M.slidingWin(framenum, plab, pdat, -11)
+            assert np.array_equal(np.asarray(veclist), ref)
+            assert np.array_equal(np.asarray(lablist), g[f"{name}_stacklab{framenum}"])
+        out_path = tmp_path / f"{name}_rt.pat"
+        M.writePatData(str(out_path), data.T)
+        assert out_path.read_bytes() == g[f"{name}_pat_bytes"].tobytes()
+
+
+def test_stacking_ragged_257x17(M):
+    rng = np.random.default_rng(5)
+    counts = [1, 5, 40, 299, 8]
+    feats = rng.standard_normal((sum(counts), 257)).astype(np.float32)
+    out = M.stack_context(torch.from_numpy(feats).cuda(), 17, frame_counts=counts).cpu().numpy()
+    ref, r = [], 0
+    for n in counts:
+        ref.append(O.stack_context(feats[r:r + n], 17))
+        r += n
+    assert out.shape == (sum(counts), 17 * 257) and np.array_equal(out, np.concatenate(ref))
+    with pytest.raises(Exception):
+        M.stack_context(feats, 16)
+
+
+# ----------------------------------------------------------------------------------------
+# CMVN
+# ----------------------------------------------------------------------------------------
+def test_cmvn_sums_and_apply(M):
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal((70001, 39)) * 5 + 3).astype(np.float32)
+    t = torch.from_numpy(x).cuda()
+    sums = M.cmvn_accumulate(t)
+    sums = M.cmvn_accumulate(t[:1000], sums)
+    n, s, ss = O.cmvn_sums(np.concatenate([x, x[:1000]]))
+    got = sums.cpu().numpy()
+    assert got[0] == n
+    assert np.allclose(got[1:40], s, rtol=1e-12, atol=1e-7) and np.allclose(got[40:], ss, rtol=1e-12)
+    mm, vv = M.cmvn_constants(sums)
+    rmm, rvv = O.cmvn_constants(n, s, ss)
+    assert np.allclose(mm.cpu().numpy(), rmm, rtol=1e-6) and np.allclose(vv.cpu().numpy(), rvv, rtol=1e-6)
+    y = M.cmvn_apply(t.clone(), mm, vv).cpu().numpy()
+    assert np.abs(y - O.cmvn_apply(x, rmm, rvv)).max() < 1e-5
+
+
+def test_error_behaviour(M):
+    with pytest.raises(Exception, match="400/160/512"):
+        M.mfcc39(np.zeros(1000, dtype=np.int16), fs=8000)
+    with pytest.raises(Exception, match="length"):
+        M.MFCC("self5")(torch.zeros(10, dtype=torch.int16, device="cuda"), lengths=[10, 0])
+    with pytest.raises(ValueError):
+        M.MFCC("self5").forward(torch.zeros(10, dtype=torch.int16), None)
