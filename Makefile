@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 LIB   := mfcc_amd/lib/libmfcc_amd.so
 SRC   := mfcc_amd/csrc/mfcc_amd.hip
 HDRS  := $(wildcard mfcc_amd/csrc/*.h) include/mfcc_amd.h
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fno-signed-zeros -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fno-signed-zeros -fno-slp-vectorize -Wall -Wno-unused-function
 
 all: $(LIB) host_sim
 
@@ -17,11 +17,16 @@ host_sim: tests/host_sim/fft_sim
 tests/host_sim/fft_sim: tests/host_sim/fft_sim.cpp mfcc_amd/csrc/fft_lane.h mfcc_amd/csrc/tables.h
 	g++ -O2 -std=c++17 -I mfcc_amd/csrc -o $@ $<
 
+# experimental builds for A/B timing: make variant NAME=noslp EXTRA="-fno-slp-vectorize"
+variant: $(SRC) $(HDRS)
+	@mkdir -p build/variants
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -o build/variants/libmfcc_$(NAME).so $(SRC)
+
 asm: $(SRC) $(HDRS)
 	@mkdir -p build
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-signed-zeros -S --cuda-device-only -o build/mfcc_amd.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-signed-zeros -fno-slp-vectorize -S --cuda-device-only -o build/mfcc_amd.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
 
 clean:
 	rm -rf mfcc_amd/lib build tests/host_sim/fft_sim
 
-.PHONY: all host_sim asm clean
+.PHONY: all host_sim asm clean variant

@@ -89,7 +89,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950) "
             "or python -c 'import __graft_entry__ as g; g.build()'. There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -50,9 +51,9 @@ struct mfcc_plan {
   int device;
   int32_t frame_size, frame_step, nfft;
   float* tw512 = nullptr;
-  float* melw = nullptr;
-  int2* melrange = nullptr;
-  float* dctw = nullptr;
+  mfcc::MelMap map;
+  float* melB = nullptr;
+  float* dctB = nullptr;
   float* window = nullptr;
   float pre_hi, pre_lo, spec_scale;
 };
@@ -143,23 +144,81 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   // spectrum rows in LDS hold 4|X|^2 (power) or 2|X| (magnitude); both scales are powers of two
   p->spec_scale = cfg->spectrum == MFCC_SPECTRUM_POWER ? 1.0f / (4.0f * nfft) : 0.5f;
 
+  // ---- operands of the two matrix-core products (layout: see mfcc::MelMap) ----------------
   const int nmel = cfg->num_bins;
   const std::vector<double> bank = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft);
-  std::vector<float> melw((size_t)nmel * mfcc::kMelLd, 0.f);
-  std::vector<int2> range(nmel);
-  for (int j = 0; j < nmel; ++j) {
-    int first = -1, last = -1;
-    for (int k = 0; k < mfcc::kNbin; ++k) {
-      const double w = bank[(size_t)j * mfcc::kNbin + k];
-      melw[(size_t)j * mfcc::kMelLd + k] = (float)(w * (double)p->spec_scale);
-      if (w != 0.0) { if (first < 0) first = k; last = k; }
-    }
-    range[j] = first < 0 ? make_int2(0, 0) : make_int2(first, last - first + 1);
+  std::vector<int> first(nmel, mfcc::kNbin), last(nmel, -1);
+  for (int m = 0; m < nmel; ++m)
+    for (int k = 0; k < mfcc::kNbin; ++k)
+      if (bank[(size_t)m * mfcc::kNbin + k] != 0.0) {
+        first[m] = std::min(first[m], k);
+        last[m] = std::max(last[m], k);
+      }
+  // Split the filters into 4 contiguous column groups (one per wave, <= 15 each, may be empty)
+  // so that the longest bin range any wave has to walk is shortest.  Every bin also adds to
+  // the energy column of exactly one wave: group g takes bins [estart[g], estart[g+1]).
+  int best_cut[5] = {0, 0, 0, 0, nmel}, best_max = 1 << 30, best_sum = 1 << 30;
+  int best_k0[4] = {0, 0, 0, 0}, best_es[5] = {0, 0, 0, 0, mfcc::kNbin};
+  for (int c1 = 0; c1 <= nmel; ++c1)
+    for (int c2 = c1; c2 <= nmel; ++c2)
+      for (int c3 = c2; c3 <= nmel; ++c3) {
+        const int cut[5] = {0, c1, c2, c3, nmel};
+        bool ok = true;
+        int fb[4], lb[4];
+        for (int g = 0; g < 4 && ok; ++g) {
+          if (cut[g + 1] - cut[g] > mfcc::kMelCols) ok = false;
+          fb[g] = mfcc::kNbin;
+          lb[g] = -1;
+          for (int m = cut[g]; m < cut[g + 1]; ++m) { fb[g] = std::min(fb[g], first[m]); lb[g] = std::max(lb[g], last[m]); }
+        }
+        if (!ok) continue;
+        int es[5];
+        es[0] = 0;
+        for (int g = 1; g < 4; ++g) es[g] = std::max(es[g - 1], std::min(fb[g], mfcc::kNbin));
+        es[4] = mfcc::kNbin;
+        int mx = 0, sum = 0, k0[4];
+        for (int g = 0; g < 4; ++g) {
+          const int lo = std::min(es[g], fb[g]), hi = std::max(lb[g] + 1, es[g + 1]);
+          k0[g] = std::min(lo, hi);
+          const int st = hi > lo ? (hi - lo + 3) / 4 : 0;
+          mx = std::max(mx, st);
+          sum += st;
+        }
+        if (mx < best_max || (mx == best_max && sum < best_sum)) {
+          best_max = mx; best_sum = sum;
+          for (int g = 0; g < 5; ++g) { best_cut[g] = cut[g]; best_es[g] = es[g]; }
+          for (int g = 0; g < 4; ++g) best_k0[g] = k0[g];
+        }
+      }
+  if (best_max > mfcc::kMelSteps) {
+    delete p;
+    return fail(MFCC_ERR_UNSUPPORTED, "filterbank needs %d MFMA k-steps per wave, the kernel provides %d", best_max, mfcc::kMelSteps);
   }
+  memset(&p->map, 0, sizeof(p->map));
+  std::vector<float> melB((size_t)4 * mfcc::kMelSteps * 64, 0.f);
+  for (int g = 0; g < 4; ++g) {
+    p->map.kstart[g] = std::min(best_k0[g], mfcc::kNbin - 1);
+    p->map.first_filter[g] = best_cut[g];
+    p->map.nfilt[g] = best_cut[g + 1] - best_cut[g];
+    for (int sidx = 0; sidx < mfcc::kMelSteps; ++sidx)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int k = p->map.kstart[g] + 4 * sidx + (lane >> 4), j = lane & 15;
+        double w = 0.0;
+        if (k < mfcc::kNbin) {
+          if (j < p->map.nfilt[g]) w = bank[(size_t)(best_cut[g] + j) * mfcc::kNbin + k];
+          else if (j == mfcc::kMelCols && k >= best_es[g] && k < best_es[g + 1]) w = 1.0;
+        }
+        melB[((size_t)g * mfcc::kMelSteps + sidx) * 64 + lane] = (float)(w * (double)p->spec_scale);
+      }
+  }
+  p->map.ndct = (nmel + 3) / 4;
   const std::vector<double> dl = mfcc::dct_lifter(nmel, cfg->numcep, cfg->lift_factor, true);
-  std::vector<float> dctw((size_t)nmel * mfcc::kMaxCep, 0.f);
-  for (int j = 0; j < nmel; ++j)
-    for (int c = 0; c < cfg->numcep; ++c) dctw[(size_t)j * mfcc::kMaxCep + c] = (float)dl[(size_t)j * cfg->numcep + c];
+  std::vector<float> dctB((size_t)mfcc::kDctSteps * 64, 0.f);
+  for (int sidx = 0; sidx < p->map.ndct; ++sidx)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = 4 * sidx + (lane >> 4), c = lane & 15;
+      if (m < nmel && c < cfg->numcep) dctB[(size_t)sidx * 64 + lane] = (float)dl[(size_t)m * cfg->numcep + c];
+    }
   std::vector<float> win;
   if (cfg->window == MFCC_WINDOW_HAMMING) {
     const std::vector<double> h = mfcc::hamming(size);
@@ -167,8 +226,8 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
     for (int n = 0; n < size; ++n) win[n] = (float)h[n];
   }
   int rc;
-  if ((rc = upload(mfcc::twiddle512(), &p->tw512)) || (rc = upload(melw, &p->melw)) ||
-      (rc = upload(range, &p->melrange)) || (rc = upload(dctw, &p->dctw)) || (rc = upload(win, &p->window))) {
+  if ((rc = upload(mfcc::twiddle512(), &p->tw512)) ||
+      (rc = upload(melB, &p->melB)) || (rc = upload(dctB, &p->dctB)) || (rc = upload(win, &p->window))) {
     mfcc_plan_destroy(p);
     return rc;
   }
@@ -179,9 +238,8 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
 int mfcc_plan_destroy(mfcc_plan* p) {
   if (!p) return MFCC_OK;
   (void)hipFree(p->tw512);
-  (void)hipFree(p->melw);
-  (void)hipFree(p->melrange);
-  (void)hipFree(p->dctw);
+  (void)hipFree(p->melB);
+  (void)hipFree(p->dctB);
   (void)hipFree(p->window);
   delete p;
   return MFCC_OK;
@@ -221,6 +279,7 @@ int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64
   l->sample_off.assign(n_utts + 1, 0);
   l->frame_off.assign(n_utts + 1, 0);
   std::vector<mfcc::Tile> tiles;
+  const int64_t tile_max = mfcc::tile_frames_for(plan->cfg.numcep);
   for (int64_t u = 0; u < n_utts; ++u) {
     const int64_t len = lengths_host[u];
     if (len < 1) {
@@ -235,10 +294,14 @@ int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64
     }
     l->sample_off[u + 1] = l->sample_off[u] + len;
     l->frame_off[u + 1] = l->frame_off[u] + nf;
-    const int64_t ntile = (nf + mfcc::kTileFrames - 1) / mfcc::kTileFrames;
-    for (int64_t i = 0; i < ntile; ++i) {
-      const int64_t a = i * nf / ntile, b = (i + 1) * nf / ntile;
-      tiles.push_back(mfcc::Tile{(int32_t)u, (int32_t)a, (int32_t)(b - a), 0});
+    // greedy tiling: every tile computes a whole number of 16-frame batches where it can
+    // (tile frames + 4 halo frames on each side that continues)
+    for (int64_t t = 0; t < nf;) {
+      const int64_t left = t > 0 ? mfcc::kHalo : 0;
+      int64_t nt = nf - t;
+      if (nt + left > tile_max) nt = tile_max - left - mfcc::kHalo;
+      tiles.push_back(mfcc::Tile{(int32_t)u, (int32_t)t, (int32_t)nt, 0});
+      t += nt;
     }
   }
   l->total_samples = l->sample_off[n_utts];
@@ -309,9 +372,10 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   fp.out = out;
   fp.out_ld = out_ld;
   fp.tw512 = plan->tw512;
-  fp.melw = plan->melw;
-  fp.melrange = plan->melrange;
-  fp.dctw = plan->dctw;
+  fp.total_elems = layout->total_samples;
+  fp.map = plan->map;
+  fp.melB = plan->melB;
+  fp.dctB = plan->dctB;
   fp.window = plan->window;
   fp.nmel = plan->cfg.num_bins;
   fp.numcep = plan->cfg.numcep;
@@ -326,12 +390,19 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   const dim3 grid((unsigned)layout->n_tiles), block(256);
   const size_t smem = mfcc::kSmemFloats * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  const bool c13 = plan->cfg.numcep == 13;
   switch (out_kind) {
-    case MFCC_OUT_MFCC39: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutMfcc39>, grid, block, smem, st, fp); break;
-    case MFCC_OUT_STATIC: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutStatic>, grid, block, smem, st, fp); break;
-    case MFCC_OUT_LOGMEL: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutLogmel>, grid, block, smem, st, fp); break;
-    case MFCC_OUT_SPEC: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutSpec>, grid, block, smem, st, fp); break;
-    case MFCC_OUT_LOGSPEC: hipLaunchKernelGGL(mfcc::fused_kernel<mfcc::kOutLogspec>, grid, block, smem, st, fp); break;
+    case MFCC_OUT_MFCC39:
+      if (c13) hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutMfcc39, 13>), grid, block, smem, st, fp);
+      else hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutMfcc39, 0>), grid, block, smem, st, fp);
+      break;
+    case MFCC_OUT_STATIC:
+      if (c13) hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutStatic, 13>), grid, block, smem, st, fp);
+      else hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutStatic, 0>), grid, block, smem, st, fp);
+      break;
+    case MFCC_OUT_LOGMEL: hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutLogmel, 0>), grid, block, smem, st, fp); break;
+    case MFCC_OUT_SPEC: hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutSpec, 0>), grid, block, smem, st, fp); break;
+    case MFCC_OUT_LOGSPEC: hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutLogspec, 0>), grid, block, smem, st, fp); break;
   }
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
