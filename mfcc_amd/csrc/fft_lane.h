@@ -10,8 +10,15 @@
 //   untangle             :  X[k], X[256-k] from Z[k], Z[256-k]  (k = q + 16 k2, k2 < 8)
 //
 // This replaces the per-frame np.fft.rfft(chunk, 512) of the reference
-// (mfcc-self5.py:96).  Everything here is plain C++ so that the same code is
-// exercised lane by lane on the host by tests/host_sim.
+// (mfcc-self5.py:96).
+//
+// A complex value is one 64-bit register pair and every butterfly is written with the
+// packed-f32 instructions of gfx950 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): on this
+// chip a packed instruction costs about 1.25x a scalar one and does twice the work.  Swaps
+// and sign flips (multiplication by -i, conjugation) ride on the op_sel / neg modifiers of
+// the packed instruction that consumes them, which hipcc does not fold by itself, hence
+// the inline assembly.  On the host the same functions are plain C++ so that
+// tests/host_sim exercises the identical index logic lane by lane.
 #pragma once
 
 #if defined(__HIPCC__)
@@ -22,58 +29,119 @@
 
 namespace mfcc {
 
+#if defined(__clang__)
+typedef float cf __attribute__((ext_vector_type(2)));
+MFCC_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+#else
+struct cf {
+  float x, y;
+};
+MFCC_HD cf mk(float x, float y) { return cf{x, y}; }
+MFCC_HD cf operator+(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+MFCC_HD cf operator-(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+MFCC_HD cf operator*(cf a, cf b) { return cf{a.x * b.x, a.y * b.y}; }
+#endif
+
 constexpr float kC1 = 0.92387953251128674f;  // cos(pi/8)
 constexpr float kS1 = 0.38268343236508977f;  // sin(pi/8)
 constexpr float kR2 = 0.70710678118654752f;  // sqrt(1/2)
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cf add_mi(cf a, cf b) {
+  cf d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf sub_mi(cf a, cf b) {
+  cf d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// a + conj(b)
+__device__ __forceinline__ cf add_conj(cf a, cf b) {
+  cf d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// a - conj(b)
+__device__ __forceinline__ cf sub_conj(cf a, cf b) {
+  cf d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// (-i) a = (a.y, -a.x)
+__device__ __forceinline__ cf mul_mi(cf a) {
+  cf d;
+  asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(a));
+  return d;
+}
+// a * w, w in vector registers (lane-dependent twiddle)
+__device__ __forceinline__ cf cmul(cf a, cf w) {
+  cf t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+  return d;
+}
+// a * w, w wave-uniform (scalar register pair)
+__device__ __forceinline__ cf cmulk(cf a, cf w) {
+  cf t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+  return d;
+}
+// |a|^2
+__device__ __forceinline__ float norm2(cf a) {
+  const cf t = a * a;
+  return t.x + t.y;
+}
+#else
+MFCC_HD cf add_mi(cf a, cf b) { return mk(a.x + b.y, a.y - b.x); }
+MFCC_HD cf sub_mi(cf a, cf b) { return mk(a.x - b.y, a.y + b.x); }
+MFCC_HD cf add_conj(cf a, cf b) { return mk(a.x + b.x, a.y - b.y); }
+MFCC_HD cf sub_conj(cf a, cf b) { return mk(a.x - b.x, a.y + b.y); }
+MFCC_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }
+MFCC_HD cf cmul(cf a, cf w) { return mk(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+MFCC_HD cf cmulk(cf a, cf w) { return cmul(a, w); }
+MFCC_HD float norm2(cf a) { return a.x * a.x + a.y * a.y; }
+#endif
+
 // Forward radix-4 butterfly, in place:
 //   a0' = a0+a1+a2+a3, a1' = a0 - i a1 - a2 + i a3, a2' = a0-a1+a2-a3, a3' = a0 + i a1 - a2 - i a3
-MFCC_HD void radix4(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2, float& r3, float& i3) {
-  const float t0r = r0 + r2, t0i = i0 + i2;
-  const float t1r = r0 - r2, t1i = i0 - i2;
-  const float t2r = r1 + r3, t2i = i1 + i3;
-  const float t3r = r1 - r3, t3i = i1 - i3;
-  r0 = t0r + t2r; i0 = t0i + t2i;
-  r2 = t0r - t2r; i2 = t0i - t2i;
-  r1 = t1r + t3i; i1 = t1i - t3r;
-  r3 = t1r - t3i; i3 = t1i + t3r;
-}
-
-MFCC_HD void cmul(float& r, float& i, const float wr, const float wi) {
-  const float nr = r * wr - i * wi;
-  const float ni = r * wi + i * wr;
-  r = nr; i = ni;
+MFCC_HD void radix4(cf& a0, cf& a1, cf& a2, cf& a3) {
+  const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = add_mi(t1, t3);
+  a3 = sub_mi(t1, t3);
 }
 
 // 16-point forward DFT, natural order in and out, all indices compile-time.
 // x[n], n = 4a + b;  X[c + 4d] = sum_b W4^(bd) W16^(bc) sum_a x[4a+b] W4^(ac).
-MFCC_HD void fft16(float (&xr)[16], float (&xi)[16]) {
+MFCC_HD void fft16(cf (&x)[16]) {
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
-    radix4(xr[b], xi[b], xr[4 + b], xi[4 + b], xr[8 + b], xi[8 + b], xr[12 + b], xi[12 + b]);
-  // after the first pass xr[4c + b] holds Y_b[c]; twiddle by W16^(bc), W16^m = (cos, -sin)(2 pi m / 16)
-  cmul(xr[4 + 1], xi[4 + 1], kC1, -kS1);    // b=1 c=1  m=1
-  cmul(xr[8 + 1], xi[8 + 1], kR2, -kR2);    // b=1 c=2  m=2
-  cmul(xr[12 + 1], xi[12 + 1], kS1, -kC1);  // b=1 c=3  m=3
-  cmul(xr[4 + 2], xi[4 + 2], kR2, -kR2);    // b=2 c=1  m=2
-  {                                         // b=2 c=2  m=4 : multiply by -i
-    const float t = xr[8 + 2]; xr[8 + 2] = xi[8 + 2]; xi[8 + 2] = -t;
-  }
-  cmul(xr[12 + 2], xi[12 + 2], -kR2, -kR2);  // b=2 c=3  m=6
-  cmul(xr[4 + 3], xi[4 + 3], kS1, -kC1);     // b=3 c=1  m=3
-  cmul(xr[8 + 3], xi[8 + 3], -kR2, -kR2);    // b=3 c=2  m=6
-  cmul(xr[12 + 3], xi[12 + 3], -kC1, kS1);   // b=3 c=3  m=9
+  for (int b = 0; b < 4; ++b) radix4(x[b], x[4 + b], x[8 + b], x[12 + b]);
+  // after the first pass x[4c + b] holds Y_b[c]; twiddle by W16^(bc), W16^m = (cos, -sin)(2 pi m / 16)
+  x[4 + 1] = cmulk(x[4 + 1], mk(kC1, -kS1));     // b=1 c=1  m=1
+  x[8 + 1] = cmulk(x[8 + 1], mk(kR2, -kR2));     // b=1 c=2  m=2
+  x[12 + 1] = cmulk(x[12 + 1], mk(kS1, -kC1));   // b=1 c=3  m=3
+  x[4 + 2] = cmulk(x[4 + 2], mk(kR2, -kR2));     // b=2 c=1  m=2
+  x[8 + 2] = mul_mi(x[8 + 2]);                   // b=2 c=2  m=4
+  x[12 + 2] = cmulk(x[12 + 2], mk(-kR2, -kR2));  // b=2 c=3  m=6
+  x[4 + 3] = cmulk(x[4 + 3], mk(kS1, -kC1));     // b=3 c=1  m=3
+  x[8 + 3] = cmulk(x[8 + 3], mk(-kR2, -kR2));    // b=3 c=2  m=6
+  x[12 + 3] = cmulk(x[12 + 3], mk(-kC1, kS1));   // b=3 c=3  m=9
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-    radix4(xr[4 * c], xi[4 * c], xr[4 * c + 1], xi[4 * c + 1], xr[4 * c + 2], xi[4 * c + 2], xr[4 * c + 3],
-           xi[4 * c + 3]);
-  // xr[4c + d] now holds X[c + 4d]: transpose the 4x4 index grid (register renaming only)
+  for (int c = 0; c < 4; ++c) radix4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+  // x[4c + d] now holds X[c + 4d]: transpose the 4x4 index grid (register renaming only)
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int d = c + 1; d < 4; ++d) {
-      float t = xr[4 * c + d]; xr[4 * c + d] = xr[4 * d + c]; xr[4 * d + c] = t;
-      t = xi[4 * c + d]; xi[4 * c + d] = xi[4 * d + c]; xi[4 * d + c] = t;
+      const cf t = x[4 * c + d];
+      x[4 * c + d] = x[4 * d + c];
+      x[4 * d + c] = t;
     }
 }
 
@@ -85,19 +153,16 @@ MFCC_HD int xpose_index(int k1, int n2) { return k1 * 16 + (n2 ^ (k1 & 14)); }
 // Lane that holds Z[256 - k] for the k values of lane q.
 MFCC_HD int partner_lane(int q) { return (16 - q) & 15; }
 
-// One untangle step.  (ar, ai) = Z[k], (br, bi) = Z[256-k], (wr, wi) = W512^k.
+// One untangle step.  a = Z[k], b = Z[256-k], w = W512^k.
 // Returns 4|X[k]|^2 in p_lo and 4|X[256-k]|^2 in p_hi:
 //   2 X[k]       = A - i W B,   2 conj X[256-k] = A + i W B,
 //   A = Z[k] + conj Z[256-k],   B = Z[k] - conj Z[256-k].
-MFCC_HD void untangle_power(float ar, float ai, float br, float bi, float wr, float wi, float& p_lo, float& p_hi) {
-  const float Ar = ar + br, Ai = ai - bi;
-  const float Br = ar - br, Bi = ai + bi;
-  const float Cr = wr * Br - wi * Bi;
-  const float Ci = wr * Bi + wi * Br;
-  const float x0r = Ar + Ci, x0i = Ai - Cr;
-  const float x1r = Ar - Ci, x1i = Ai + Cr;
-  p_lo = x0r * x0r + x0i * x0i;
-  p_hi = x1r * x1r + x1i * x1i;
+MFCC_HD void untangle_power(cf a, cf b, cf w, float& p_lo, float& p_hi) {
+  const cf A = add_conj(a, b);
+  const cf B = sub_conj(a, b);
+  const cf C = cmul(B, w);
+  p_lo = norm2(add_mi(A, C));
+  p_hi = norm2(sub_mi(A, C));
 }
 
 }  // namespace mfcc

@@ -42,7 +42,7 @@ constexpr int kNbin = kNfft / 2 + 1;
 constexpr int kBatch = 16;        // frames per batch (4 waves x 4 frames)
 constexpr int kHalo = 4;          // delta-delta reach: 2 * pad_fac
 constexpr int kMaxCep = 16;
-constexpr int kMaxMel = 44;
+constexpr int kMaxMel = 40;       // "26-40 Mel bins" (mfcc-self5.py:23); bounds the LDS tables
 constexpr int kStage = (kBatch - 1) * kFrameStep + kFrameSize;  // 2800 samples per batch
 constexpr int kMelCols = 15;      // filter columns per wave; column 15 carries the wave's energy partial
 constexpr int kMelSteps = 24;     // MFMA k-steps (4 bins each) per wave, upper bound
@@ -51,12 +51,16 @@ constexpr int kDctSteps = (kMaxMel + 3) / 4;
 // LDS carve (floats).
 constexpr int kSlot = 514;                           // spectrum row of frame f starts at f*514
 constexpr int kXbufFloats = kBatch * kSlot;          // exchange buffers (fb*512) / spectrum rows; epilogue scratch
-constexpr int kAbufFloats = 2816;                    // staged audio: kStage + up to 7 alignment samples
-constexpr int kLogPitch = 48;                        // ln-mel row of a frame: nmel values, ln E at [nmel]
+constexpr int kAbufFloats = 2808;                    // staged audio: kStage + up to 7 alignment samples, whole chunks
+constexpr int kLogPitch = 49;                        // ln-mel row of a frame (odd pitch: conflict-free column reads)
 constexpr int kLbufFloats = kBatch * kLogPitch;
 constexpr int kEpFloats = 4 * kBatch;                // energy partial of wave w for frame f at [w*16 + f]
 constexpr int kHbufFloats = 2 * kHalo * kMaxCep;     // static features of the halo frames
-constexpr int kSmemFloats = kXbufFloats + kAbufFloats + kLbufFloats + kEpFloats + kHbufFloats;
+constexpr int kDctBFloats = kDctSteps * 64;          // B operands of the DCT product, shared by the 4 waves
+constexpr int kTwPitch = 46;                         // per-lane-index twiddle row: 15 + 8 complex values
+constexpr int kTwFloats = 16 * kTwPitch;             // rows for q = 0..15 (46 q mod 64 are distinct even banks)
+constexpr int kSmemFloats =
+    kXbufFloats + kAbufFloats + kLbufFloats + kEpFloats + kHbufFloats + kDctBFloats + kTwFloats;
 
 constexpr float kEps64 = 2.220446049250313e-16f;     // np.finfo(float).eps, mfcc-self5.py:131
 
@@ -85,6 +89,23 @@ struct MelMap {
   int32_t ndct;  // k-steps of the DCT product = ceil(nmel / 4)
 };
 
+// Per-plan constants, resident in device memory; read with scalar loads where needed so
+// that they do not occupy scalar registers across the batch loop.
+struct PlanConst {
+  const float* tw512;     // [512][2]  exp(-2 pi i m / 512)
+  const float* melB;      // [4][kMelSteps][64] B operands (filter weights * spec_scale) in lane order
+  const float* dctB;      // [kDctSteps][64] B operands of the DCT*lifter product in lane order
+  const float* window;    // [512] or nullptr
+  MelMap map;
+  int32_t mel_steps[4];   // k-steps wave w really needs (<= kMelSteps)
+  int32_t nmel;
+  int32_t numcep;
+  float pre_hi, pre_lo;   // pre-emphasis coefficient split in two floats (hi + lo ~ double value); 0, 0 = off
+  int32_t spectrum;       // 0 power, 1 magnitude
+  int32_t floor_mel;
+  float spec_scale;       // 1/(4*nfft) for power, 1/2 for magnitude (both exact powers of two)
+};
+
 struct FusedParams {
   const void* audio;
   int64_t total_elems;        // elements in `audio` (bounds the 16-byte staging loads)
@@ -93,20 +114,20 @@ struct FusedParams {
   const Tile* tiles;
   float* out;
   int64_t out_ld;
-  const float* tw512;     // [512][2]  exp(-2 pi i m / 512)
-  const float* melB;      // [4][kMelSteps][64] B operands (filter weights * spec_scale) in lane order
-  const float* dctB;      // [kDctSteps][64] B operands of the DCT*lifter product in lane order
-  const float* window;    // [512] or nullptr
-  MelMap map;
-  int32_t nmel;
-  int32_t numcep;
-  int32_t audio_dtype;    // 0 = int16, 1 = float32
-  int32_t use_preemph;
-  float pre_hi, pre_lo;   // coefficient split in two floats (hi + lo ~ double value)
-  int32_t spectrum;       // 0 power, 1 magnitude
-  int32_t floor_mel;
-  float spec_scale;       // 1/(4*nfft) for power, 1/2 for magnitude (both exact powers of two)
+  const PlanConst* pc;
+  int32_t audio_dtype;        // 0 = int16, 1 = float32
+#ifdef MFCC_DIAG
+  unsigned long long* dbg;    // [n_tiles][4 waves][8] cycle sums
+#endif
 };
+
+#ifdef MFCC_DIAG
+// Diagnostic build only: per-wave cycle sums of the phases of the batch loop, written to a
+// buffer of their own (never to an output element).
+#define MFCC_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define MFCC_STAMP(var)
+#endif
 
 enum : int { kOutMfcc39 = 0, kOutStatic = 1, kOutLogmel = 2, kOutSpec = 3, kOutLogspec = 4 };
 
@@ -120,82 +141,124 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ln x from the hardware log2 (v_log_f32, 1 ulp): relative error ~2e-7 for the mel energies
+// (x >> denormal range); ln 0 = -inf as numpy's.
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+
 __device__ __forceinline__ float lane_read(int byte_addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
 
-// Stage the samples of one 16-frame batch into LDS as float, pre-emphasised, zero beyond the
-// utterance end (mfcc-self5.py:68 and :89-90).  Global memory is read in aligned 16-byte
-// chunks; the LDS image keeps the chunk alignment, i.e. sample i of the batch sits at
-// abuf[delta + i] where delta = (address of the batch's first sample) mod 16 bytes, in elements.
+// Staging of one 16-frame batch into LDS as float, pre-emphasised, zero beyond the utterance
+// end (mfcc-self5.py:68 and :89-90).  Global memory is read in aligned 16-byte chunks; the LDS
+// image keeps the chunk alignment, i.e. sample i of the batch sits at abuf[delta + i] where
+// delta = (address of the batch's first sample) mod 16 bytes, in elements.  The global loads
+// (stage_load) are issued a phase before their results are converted and written
+// (stage_store), so that the HBM latency is covered by the matrix-core work in between.
+struct StageRegs {
+  uint4 raw[3];   // chunks per thread: ceil((7 + 2800) / 8 / 256) = 2 for int16, 3 for float32
+  float prev[3];  // sample in front of each chunk
+  int delta;
+};
+
 template <typename T>
-__device__ __forceinline__ int stage_audio(const FusedParams& p, float* abuf, int64_t s_off, int64_t len, int tb,
-                                           int tid) {
+__device__ __forceinline__ void stage_load(const T* utt, int64_t before, int64_t after, StageRegs& r, int tb, int tid) {
+  // utt = first sample of the utterance; `before` / `after` = elements of the audio buffer in
+  // front of it / from it to the end of the buffer (bounds for the aligned loads)
   constexpr int CE = 16 / (int)sizeof(T);  // elements per chunk
-  const T* base = (const T*)p.audio;
-  const int64_t g0 = s_off + (int64_t)tb * kFrameStep;  // first sample of the batch, in elements of `audio`
-  const uintptr_t addr = (uintptr_t)(base + g0);
-  const int delta = (int)((addr & 15) / sizeof(T));
-  const T* a0 = (const T*)(addr & ~(uintptr_t)15);      // aligned chunk 0
+  constexpr int NR = sizeof(T) == 2 ? 2 : 3;
+  const T* b0 = utt + (int64_t)tb * kFrameStep;  // first sample of the batch
+  const int delta = (int)(((uintptr_t)b0 & 15) / sizeof(T));
+  const T* a0 = b0 - delta;                      // aligned chunk 0 (pointer arithmetic keeps it a global pointer)
   constexpr int kBig = 1 << 20;
-  // chunk-relative element range that lies inside `audio`, and inside this utterance
-  const int64_t lo64 = -(g0 - delta), hi64 = p.total_elems - (g0 - delta);
-  const int e_lo = lo64 < -kBig ? -kBig : (int)lo64;
+  const int64_t lo64 = -(before + (int64_t)tb * kFrameStep - delta);
+  const int64_t hi64 = after - (int64_t)tb * kFrameStep + delta;
+  const int e_lo = lo64 < -kBig ? -kBig : (int)lo64;  // chunk-relative element range inside the audio buffer
   const int e_hi = hi64 > kBig ? kBig : (int)hi64;
+  const int nchunk = (delta + kStage + CE - 1) / CE;
+  r.delta = delta;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int c = tid + 256 * k;
+    const int e0 = c * CE;
+    r.raw[k] = make_uint4(0, 0, 0, 0);
+    r.prev[k] = 0.f;
+    if (c < nchunk) {
+      if (e0 > e_lo && e0 + CE <= e_hi) {  // chunk and its predecessor sample lie inside the buffer
+        r.raw[k] = *(const uint4*)(a0 + e0);
+        r.prev[k] = (float)a0[e0 - 1];
+      } else {  // chunk straddles an end of the buffer: element-wise, zero outside
+        T tmp[CE];
+#pragma unroll
+        for (int j = 0; j < CE; ++j) tmp[j] = (e0 + j >= e_lo && e0 + j < e_hi) ? a0[e0 + j] : (T)0;
+        r.raw[k] = *(const uint4*)tmp;
+        if (e0 - 1 >= e_lo && e0 - 1 < e_hi) r.prev[k] = (float)a0[e0 - 1];
+      }
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int64_t len, int tb, int tid,
+                                            float pre_hi, float pre_lo) {
+  constexpr int CE = 16 / (int)sizeof(T);
+  constexpr int NR = sizeof(T) == 2 ? 2 : 3;
+  constexpr int kBig = 1 << 20;
+  const int delta = r.delta;
   const int64_t rem64 = len - (int64_t)tb * kFrameStep;  // samples of this utterance from the batch start on
   const int i_hi = delta + (rem64 > kBig ? kBig : (int)rem64);
-  const int i_first = tb == 0 ? delta : -kBig;           // element whose predecessor is not part of the signal
   const int nchunk = (delta + kStage + CE - 1) / CE;
-  const bool pre = p.use_preemph != 0;
-  for (int c = tid; c < nchunk; c += 256) {
+  // interior batch: no utterance start, no utterance end inside the staged range
+  const bool interior = tb > 0 && i_hi >= nchunk * CE;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int c = tid + 256 * k;
+    if (c >= nchunk) break;
     const int e0 = c * CE;
     float x[CE + 1];
-    if (e0 >= e_lo && e0 + CE <= e_hi) {
-      const uint4 raw = *(const uint4*)(a0 + e0);
-      if (sizeof(T) == 2) {
-        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    x[0] = r.prev[k];
+    const unsigned w[4] = {r.raw[k].x, r.raw[k].y, r.raw[k].z, r.raw[k].w};
+    if (sizeof(T) == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x[1 + 2 * j] = (float)(int16_t)(w[j] & 0xffff);
-          x[2 + 2 * j] = (float)((int)w[j] >> 16);
-        }
-      } else {
-        x[1] = __uint_as_float(raw.x); x[2] = __uint_as_float(raw.y);
-        x[3] = __uint_as_float(raw.z); x[4] = __uint_as_float(raw.w);
+      for (int j = 0; j < 4; ++j) {
+        x[1 + 2 * j] = (float)(int16_t)(w[j] & 0xffff);
+        x[2 + 2 * j] = (float)((int)w[j] >> 16);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < CE; ++j) x[1 + j] = (e0 + j >= e_lo && e0 + j < e_hi) ? (float)a0[e0 + j] : 0.f;
+      for (int j = 0; j < 4; ++j) x[1 + j] = __uint_as_float(w[j]);
     }
-    x[0] = (e0 - 1 >= e_lo && e0 - 1 < e_hi) ? (float)a0[e0 - 1] : 0.f;
     float y[CE];
 #pragma unroll
     for (int j = 0; j < CE; ++j) {
-      const int e = e0 + j;
-      float v = x[j + 1];
-      if (pre) {
-        float d;
-        if (sizeof(T) == 2) d = fmaf(-p.pre_lo, x[j], fmaf(-p.pre_hi, x[j], x[j + 1]));
-        else d = __fsub_rn(x[j + 1], __fmul_rn(p.pre_hi, x[j]));  // numpy's float32 arithmetic
-        v = e == i_first ? v : d;
+      // y[n] = x[n] - c x[n-1]; for float32 input numpy evaluates this in float32 with two roundings
+      if (sizeof(T) == 2) y[j] = fmaf(-pre_lo, x[j], fmaf(-pre_hi, x[j], x[j + 1]));
+      else y[j] = __fsub_rn(x[j + 1], __fmul_rn(pre_hi, x[j]));
+    }
+    if (!interior) {
+#pragma unroll
+      for (int j = 0; j < CE; ++j) {
+        const int e = e0 + j;
+        if (tb == 0 && e == delta) y[j] = x[j + 1];  // y[0] = x[0], mfcc-self5.py:68
+        if (e >= i_hi) y[j] = 0.f;                   // zero tail, mfcc-self5.py:89-90
       }
-      y[j] = e < i_hi ? v : 0.f;  // elements below delta are never read
     }
 #pragma unroll
     for (int j = 0; j < CE; j += 4) *(float4*)(abuf + e0 + j) = make_float4(y[j], y[j + 1], y[j + 2], y[j + 3]);
   }
-  return delta;
 }
 
 // NCEP > 0 fixes numcep at compile time (cheap index arithmetic in the epilogue); 0 = runtime.
 template <int OUT, int NCEP>
 __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(128))) float smem[];
   float* const xbuf = smem;
   float* const abuf = xbuf + kXbufFloats;
   float* const lbuf = abuf + kAbufFloats;
   float* const epbuf = lbuf + kLbufFloats;
   float* const hbuf = epbuf + kEpFloats;
+  float* const dctb = hbuf + kHbufFloats;
+  float* const twl = dctb + kDctBFloats;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -204,6 +267,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const int g4 = lane >> 4;
   const int fb = wave * 4 + g4;  // frame slot inside the batch
 
+  const PlanConst* const pc = p.pc;
   const Tile tile = p.tiles[blockIdx.x];
   const int64_t s_off = p.sample_off[tile.utt];
   const int64_t len = p.sample_off[tile.utt + 1] - s_off;
@@ -212,184 +276,255 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const int t0 = tile.t0, nt = tile.nt;
   const int s_lo = (OUT == kOutMfcc39) ? max(0, t0 - kHalo) : t0;
   const int s_hi = (OUT == kOutMfcc39) ? min(nframes, t0 + nt + kHalo) : t0 + nt;
-  const int nmel = p.nmel;
-  const int ncep = NCEP > 0 ? NCEP : p.numcep;
+  const int nmel = pc->nmel;
+  const int ncep = NCEP > 0 ? NCEP : pc->numcep;
+  const int ld = (int)p.out_ld;
+  float* const out_t0 = p.out + (f_off + t0) * p.out_ld;  // row t0 of this tile; 32-bit offsets from here
+  const float pre_hi = pc->pre_hi, pre_lo = pc->pre_lo;
+  const bool mag = pc->spectrum != 0;
+  const float* const window = pc->window;
+  // this wave's share of the filterbank product
+  const int mel_k0 = pc->map.kstart[wave], mel_nf = pc->map.nfilt[wave], mel_ff = pc->map.first_filter[wave];
+  const int mel_ns = pc->mel_steps[wave];
+  const float* const melB = pc->melB + (wave * kMelSteps) * 64 + lane;
 
-  // per-lane twiddles: stage 1 uses W256^(q k1) = W512^(2 q k1), the untangle W512^(q + 16 s)
-  float tw1r[16], tw1i[16], tw2r[8], tw2i[8];
-#pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) {
-    const float2 w = *(const float2*)(p.tw512 + 2 * ((2 * q * k1) & 511));
-    tw1r[k1] = w.x; tw1i[k1] = w.y;
+  // Twiddles per lane index q: stage 1 uses W256^(q k1) = W512^(2 q k1), k1 = 1..15, the
+  // untangle W512^(q + 16 s), s = 0..7.  They live in LDS (row q, 23 complex values) and are
+  // read when needed: 46 registers per lane would cost a wave of occupancy.
+  {
+    const float* tw = pc->tw512;
+    for (int i = tid; i < 16 * 23; i += 256) {
+      const int qq = i / 23, k = i - qq * 23;
+      const int m = k < 15 ? (2 * qq * (k + 1)) & 511 : qq + 16 * (k - 15);
+      *(cf*)(twl + qq * kTwPitch + 2 * k) = *(const cf*)(tw + 2 * m);
+    }
   }
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const float2 w = *(const float2*)(p.tw512 + 2 * (q + 16 * s));
-    tw2r[s] = w.x; tw2i[s] = w.y;
-  }
+  const cf* const twq = (const cf*)(twl + q * kTwPitch);
   const int partner_addr = ((lane & 48) | partner_lane(q)) << 2;
-  const bool mag = p.spectrum != 0;
 
-  auto stage = [&](int tb) -> int {
-    return p.audio_dtype == 0 ? stage_audio<int16_t>(p, abuf, s_off, len, tb, tid)
-                              : stage_audio<float>(p, abuf, s_off, len, tb, tid);
+  StageRegs sr;
+  const bool i16 = p.audio_dtype == 0;
+  auto stage_ld = [&](int tb) {
+    if (i16) stage_load<int16_t>((const int16_t*)p.audio + s_off, s_off, p.total_elems - s_off, sr, tb, tid);
+    else stage_load<float>((const float*)p.audio + s_off, s_off, p.total_elems - s_off, sr, tb, tid);
+  };
+  auto stage_st = [&](int tb) -> int {
+    if (i16) stage_store<int16_t>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
+    else stage_store<float>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
+    return sr.delta;
   };
 
+  stage_ld(s_lo);
   // columns nmel.. of the ln-mel rows are multiplied by zero DCT weights: keep them finite
   for (int i = tid; i < kLbufFloats; i += 256) lbuf[i] = 0.f;
-  int delta = stage(s_lo);
+  {
+    const float* src = pc->dctB;
+    for (int i = tid; i < kDctBFloats; i += 256) dctb[i] = src[i];
+  }
+  int delta = stage_st(s_lo);
   __syncthreads();
 
-  int duty = 0;  // wave that runs the DCT of this batch
-  for (int tb = s_lo; tb < s_hi; tb += kBatch, duty = (duty + 1) & 3) {
+#ifdef MFCC_DIAG
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  MFCC_STAMP(tk0);
+#endif
+  for (int tb = s_lo; tb < s_hi; tb += kBatch) {
+    MFCC_STAMP(ta);
+    float bv[kMelSteps];  // B operands of this wave's filterbank k-steps, fetched at the end of the FFT section
     // ---- FFT-512 of 4 frames per wave, 16 lanes per frame -----------------------------
     {
       const float* fa = abuf + delta + fb * kFrameStep;
-      float xr[16], xi[16];
+      cf x[16];
       if (delta & 1) {  // odd sample offset: the (x[2n], x[2n+1]) pairs are not 8-byte aligned in LDS
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
           const int n = 16 * n1 + q;
           if (2 * (16 * n1) < kFrameSize) {
             const int nn = min(n, kFrameSize / 2 - 1);
-            const bool ok = 2 * n + 1 < kFrameSize;
-            const float a = fa[2 * nn], b = fa[2 * nn + 1];
-            xr[n1] = ok ? a : 0.f; xi[n1] = ok ? b : 0.f;
+            const float ok = 2 * n + 1 < kFrameSize ? 1.f : 0.f;
+            x[n1] = mk(fa[2 * nn] * ok, fa[2 * nn + 1] * ok);
           } else {
-            xr[n1] = 0.f; xi[n1] = 0.f;
+            x[n1] = mk(0.f, 0.f);
           }
         }
       } else {
-        const float2* fa2 = (const float2*)__builtin_assume_aligned(fa, 8);
+        const cf* fa2 = (const cf*)__builtin_assume_aligned(fa, 8);
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
           const int n = 16 * n1 + q;  // complex sample index: (x[2n], x[2n+1])
           if (2 * (16 * n1 + 15) + 1 < kFrameSize) {
-            const float2 v = fa2[n];
-            xr[n1] = v.x; xi[n1] = v.y;
+            x[n1] = fa2[n];
           } else if (2 * (16 * n1) < kFrameSize) {
-            const float2 v = fa2[min(n, kFrameSize / 2 - 1)];
-            const bool ok = 2 * n + 1 < kFrameSize;
-            xr[n1] = ok ? v.x : 0.f; xi[n1] = ok ? v.y : 0.f;
+            const float ok = 2 * n + 1 < kFrameSize ? 1.f : 0.f;  // staged samples are finite: 0 * v = 0
+            x[n1] = fa2[min(n, kFrameSize / 2 - 1)] * mk(ok, ok);
           } else {
-            xr[n1] = 0.f; xi[n1] = 0.f;
+            x[n1] = mk(0.f, 0.f);
           }
         }
       }
-      if (p.window) {
+      if (window) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-          if (2 * (16 * n1) < kFrameSize) {
-            const float2 w = *(const float2*)(p.window + 2 * (16 * n1 + q));
-            xr[n1] *= w.x; xi[n1] *= w.y;
-          }
-        }
+        for (int n1 = 0; n1 < 16; ++n1)
+          if (2 * (16 * n1) < kFrameSize) x[n1] = x[n1] * *(const cf*)(window + 2 * (16 * n1 + q));
       }
-      fft16(xr, xi);
-      float2* const T = (float2*)(xbuf + fb * 512);
+#ifndef MFCC_ABL_FFT
+      fft16(x);
+#endif
+      // Exchange buffer of this frame: 2 KiB at byte offset fb*2048 (the LDS carve starts at a
+      // 128-byte boundary), element Y[k1][n2] at xpose_index(k1, n2)*8.  Written out in bytes so
+      // that each swizzled address is one XOR away from a per-lane base:
+      //   write  k1*128 + ((q ^ (k1&14)) << 3)  =  (wbase ^ ((k1&14) << 3)) + k1*128
+      //   read   q*128  + (((2j) ^ (q&14)) << 3) =  rbase ^ (j << 4)
+      char* const lds0 = (char*)smem;
+      const int wbase = fb * 2048 + (q << 3);
+      const int rbase = fb * 2048 + (q << 7) + ((q & 14) << 3);
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) {
-        if (k1) cmul(xr[k1], xi[k1], tw1r[k1], tw1i[k1]);
-        T[xpose_index(k1, q)] = make_float2(xr[k1], xi[k1]);
+#ifndef MFCC_ABL_FFT
+        if (k1) x[k1] = cmul(x[k1], twq[k1 - 1]);
+#endif
+        *(cf*)(lds0 + (wbase ^ ((k1 & 14) << 3)) + k1 * 128) = x[k1];
       }
       wave_sync();
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float4 v = *(const float4*)(T + xpose_index(q, 2 * j));
-        xr[2 * j] = v.x; xi[2 * j] = v.y; xr[2 * j + 1] = v.z; xi[2 * j + 1] = v.w;
+        const float4 v = *(const float4*)(lds0 + (rbase ^ (j << 4)));
+        x[2 * j] = mk(v.x, v.y);
+        x[2 * j + 1] = mk(v.z, v.w);
       }
-      fft16(xr, xi);
+#ifndef MFCC_ABL_FFT
+      fft16(x);
+#endif
       wave_sync();  // every lane of this wave has read its row before spectrum rows overwrite it
 
       float* const P = xbuf + fb * kSlot;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        float br = lane_read(partner_addr, xr[15 - s]);
-        float bi = lane_read(partner_addr, xi[15 - s]);
-        if (q == 0) { br = xr[(16 - s) & 15]; bi = xi[(16 - s) & 15]; }
+        cf b = mk(lane_read(partner_addr, x[15 - s].x), lane_read(partner_addr, x[15 - s].y));
+        if (q == 0) b = x[(16 - s) & 15];
         float lo, hi;
-        untangle_power(xr[s], xi[s], br, bi, tw2r[s], tw2i[s], lo, hi);
+#ifndef MFCC_ABL_UNT
+        untangle_power(x[s], b, twq[15 + s], lo, hi);
+#else
+        lo = x[s].x + b.x + twq[15 + s].x; hi = x[s].y + b.y + twq[15 + s].y;
+#endif
         if (mag) { lo = __builtin_amdgcn_sqrtf(lo); hi = __builtin_amdgcn_sqrtf(hi); }
         P[q + 16 * s] = lo;
         P[256 - q - 16 * s] = hi;
       }
       if (q == 0) {  // bin 128 pairs with itself: X[128] = conj Z[128]
-        float m = 4.f * (xr[8] * xr[8] + xi[8] * xi[8]);
+        float m = 4.f * norm2(x[8]);
         if (mag) m = __builtin_amdgcn_sqrtf(m);
         P[128] = m;
         P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-step
       }
+      if (OUT != kOutSpec && OUT != kOutLogspec) {
+        // the frame registers are dead: fetch the filterbank operands now, they arrive while
+        // this wave waits at the barrier
+#pragma unroll
+        for (int s = 0; s < kMelSteps; ++s) bv[s] = melB[s * 64];
+      }
     }
+    MFCC_STAMP(tb1);
     __syncthreads();  // spectrum rows complete; staged audio no longer needed
+    MFCC_STAMP(tb2);
+    const bool more = tb + kBatch < s_hi;
 
     if (OUT == kOutSpec || OUT == kOutLogspec) {
       const int nvalid = min(kBatch, s_hi - tb);
+      const float scale = pc->spec_scale;
+      if (more) stage_ld(tb + kBatch);
       for (int idx = tid; idx < nvalid * kNbin; idx += 256) {
         const int f = idx / kNbin, k = idx - f * kNbin;
-        float v = xbuf[f * kSlot + k] * p.spec_scale;
+        float v = xbuf[f * kSlot + k] * scale;
         if (OUT == kOutLogspec) v = logf(v);
-        p.out[(f_off + tb + f) * p.out_ld + k] = v;
+        out_t0[(tb - t0 + f) * ld + k] = v;
       }
-      if (tb + kBatch < s_hi) delta = stage(tb + kBatch);
+      if (more) delta = stage_st(tb + kBatch);
       __syncthreads();
       continue;
     }
 
     // ---- mel filterbank on the matrix cores: D[frame][col] = sum_bin P[frame][bin] W[bin][col]
+#ifndef MFCC_ABL_STAGE
+    if (more) stage_ld(tb + kBatch);  // HBM latency runs under the MFMAs below
+#endif
     {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* Bw = p.melB + (wave * kMelSteps) * 64 + lane;
-      // k-steps past a wave's range (zero weights) read finite leftovers of the exchange buffer
-      const float* Prow = xbuf + q * kSlot + g4 + p.map.kstart[wave];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      const float* Prow = xbuf + q * kSlot + g4 + mel_k0;
+#ifndef MFCC_ABL_MEL
 #pragma unroll
-      for (int s = 0; s < kMelSteps; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s], Bw[s * 64], acc, 0, 0, 0);
+      for (int s = 0; s < kMelSteps; s += 4) {
+        // two accumulators: the MFMA dependency chain is half as long.  k-steps past the wave's
+        // range (up to 3 per wave) have zero weights and read finite leftovers of the buffer.
+        if (s < mel_ns) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s], bv[s], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s + 4], bv[s + 1], acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s + 8], bv[s + 2], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s + 12], bv[s + 3], acc2, 0, 0, 0);
+        }
+      }
+      acc += acc2;
+#else
+      acc[0] = Prow[0]; acc[1] = Prow[4]; acc[2] = bv[0]; acc[3] = bv[1];
+#endif
       // lane holds rows 4*g4 + r of column q: filters take ln at once (mfcc-self5.py:125-127,
       // unfloored by default: ln 0 = -inf), column 15 is this wave's share of the energy sum
-      const int nf = p.map.nfilt[wave], ff = p.map.first_filter[wave];
-      if (q < nf) {
+      if (q < mel_nf) {
+        const bool fl = pc->floor_mel != 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[r];
-          if (p.floor_mel && v == 0.f) v = kEps64;
-          lbuf[(4 * g4 + r) * kLogPitch + ff + q] = logf(v);
+          if (fl && v == 0.f) v = kEps64;
+#ifndef MFCC_ABL_LOG
+          lbuf[(4 * g4 + r) * kLogPitch + mel_ff + q] = fast_ln(v);
+#else
+          lbuf[(4 * g4 + r) * kLogPitch + mel_ff + q] = v;
+#endif
         }
       } else if (q == 15) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) epbuf[wave * kBatch + 4 * g4 + r] = acc[r];
       }
     }
-    if (tb + kBatch < s_hi) delta = stage(tb + kBatch);  // overlaps the other waves' MFMAs
+    MFCC_STAMP(tb3);
+#ifndef MFCC_ABL_STAGE
+    if (more) delta = stage_st(tb + kBatch);
+#endif
+    MFCC_STAMP(tb4);
     __syncthreads();  // ln-mel rows and energy partials complete; next batch staged
+    MFCC_STAMP(tb5);
 
     if (OUT == kOutLogmel) {
       if (tid < kBatch) {
         float e = (epbuf[tid] + epbuf[16 + tid]) + (epbuf[32 + tid] + epbuf[48 + tid]);
         if (e == 0.f) e = kEps64;
-        xbuf[tid] = logf(e);  // the exchange buffer is free until the next FFT
+        xbuf[tid] = fast_ln(e);  // the exchange buffer is free until the next FFT
       }
       __syncthreads();
       const int nvalid = min(kBatch, s_hi - tb);
       const int w = nmel + 1;
       for (int idx = tid; idx < nvalid * w; idx += 256) {
         const int f = idx / w, j = idx - f * w;
-        p.out[(f_off + tb + f) * p.out_ld + j] = j < nmel ? lbuf[f * kLogPitch + j] : xbuf[f];
+        out_t0[(tb - t0 + f) * ld + j] = j < nmel ? lbuf[f * kLogPitch + j] : xbuf[f];
       }
       __syncthreads();
       continue;
     }
 
     // ---- DCT-II * lifter on the matrix cores, c0 := ln E  (mfcc-self5.py:136-167) ----------
-    // One wave per batch; the others go on to the next batch's FFT.  lbuf/epbuf are rewritten
-    // only after the next spectrum barrier, which this wave reaches after it is done here.
-    if (wave == duty) {
-      const int nd = p.map.ndct;
+    // Every wave forms the whole 16 x 16 product (7 MFMAs) and stores the 4 rows held by its
+    // own lane group, so no wave waits for another.  lbuf/epbuf are rewritten only after the
+    // next spectrum barrier.
+#ifndef MFCC_ABL_DCT
+    {
+      const int nd = pc->map.ndct;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const float* Lr = lbuf + q * kLogPitch + g4;
 #pragma unroll
       for (int s = 0; s < kDctSteps; ++s)
-        if (s < nd) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Lr[4 * s], p.dctB[s * 64 + lane], acc, 0, 0, 0);
-      if (q < ncep) {
+        if (s < nd) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Lr[4 * s], dctb[s * 64 + lane], acc, 0, 0, 0);
+      if (g4 == wave && q < ncep) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 4 * g4 + r;
@@ -398,18 +533,38 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           if (q == 0) {  // mfcc-self5.py:130-132 and :164
             float e = (epbuf[i] + epbuf[16 + i]) + (epbuf[32 + i] + epbuf[48 + i]);
             if (e == 0.f) e = kEps64;
-            v = logf(e);
+            v = fast_ln(e);
           }
           if (t < s_hi) {
-            if (t >= t0 && t < t0 + nt) p.out[(f_off + t) * p.out_ld + q] = v;
+            if (t >= t0 && t < t0 + nt) out_t0[(t - t0) * ld + q] = v;
             else hbuf[(t < t0 ? t - s_lo : kHalo + t - (t0 + nt)) * kMaxCep + q] = v;
           }
         }
       }
     }
+#endif
+#ifdef MFCC_DIAG
+    {
+      MFCC_STAMP(tb6);
+      dsum[0] += tb1 - ta;   // FFT
+      dsum[1] += tb2 - tb1;  // wait at spectrum barrier
+      dsum[2] += tb3 - tb2;  // mel MFMA + ln
+      dsum[3] += tb4 - tb3;  // staging
+      dsum[4] += tb5 - tb4;  // wait at second barrier
+      dsum[5] += tb6 - tb5;  // DCT
+    }
+#endif
   }
+#ifdef MFCC_DIAG
+  MFCC_STAMP(tk1);
+  dsum[6] = tk1 - tk0;
+#endif
 
+#ifdef MFCC_ABL_EPI
+  if (OUT == kOutMfcc39 && nt < 0) {
+#else
   if (OUT == kOutMfcc39) {
+#endif
     // ---- epilogue: statics back from L2, delta, delta-delta, remaining columns out ----------
     __syncthreads();  // all static columns of the tile are written and visible to this workgroup
     float* const sb = xbuf;                             // [(s_hi - s_lo)][ncep]
@@ -422,7 +577,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       float v;
       if (t < t0) v = hbuf[r * kMaxCep + c];
       else if (t >= t0 + nt) v = hbuf[(kHalo + t - (t0 + nt)) * kMaxCep + c];
-      else v = p.out[(f_off + t) * p.out_ld + c];
+      else v = out_t0[(t - t0) * ld + c];
       sb[idx] = v;
     }
     __syncthreads();
@@ -455,9 +610,17 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         const float e = db[(min(t + 2, last) - d_lo) * ncep + cc];
         v = (2.f * (e - a) + (d - b) + 0.f * m) * 0.1f;
       }
-      p.out[(f_off + t) * p.out_ld + ncep + c] = v;
+      out_t0[r * ld + ncep + c] = v;
     }
   }
+#ifdef MFCC_DIAG
+  {
+    MFCC_STAMP(tk2);
+    dsum[7] = tk2 - tk0;
+    if (lane == 0 && p.dbg)
+      for (int i = 0; i < 8; ++i) p.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = dsum[i];
+  }
+#endif
 }
 
 }  // namespace mfcc

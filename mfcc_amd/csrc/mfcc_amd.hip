@@ -51,7 +51,8 @@ struct mfcc_plan {
   int device;
   int32_t frame_size, frame_step, nfft;
   float* tw512 = nullptr;
-  mfcc::MelMap map;
+  mfcc::PlanConst pc_host;
+  mfcc::PlanConst* pc = nullptr;
   float* melB = nullptr;
   float* dctB = nullptr;
   float* window = nullptr;
@@ -68,6 +69,11 @@ struct mfcc_layout {
   int32_t* d_row_utt = nullptr;
   int64_t n_tiles;
 };
+
+#ifdef MFCC_DIAG
+static unsigned long long* g_dbg = nullptr;
+extern "C" void mfcc_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p; }
+#endif
 
 extern "C" {
 
@@ -158,7 +164,7 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   // so that the longest bin range any wave has to walk is shortest.  Every bin also adds to
   // the energy column of exactly one wave: group g takes bins [estart[g], estart[g+1]).
   int best_cut[5] = {0, 0, 0, 0, nmel}, best_max = 1 << 30, best_sum = 1 << 30;
-  int best_k0[4] = {0, 0, 0, 0}, best_es[5] = {0, 0, 0, 0, mfcc::kNbin};
+  int best_k0[4] = {0, 0, 0, 0}, best_es[5] = {0, 0, 0, 0, mfcc::kNbin}, best_steps[4] = {0, 0, 0, 0};
   for (int c1 = 0; c1 <= nmel; ++c1)
     for (int c2 = c1; c2 <= nmel; ++c2)
       for (int c3 = c2; c3 <= nmel; ++c3) {
@@ -176,45 +182,48 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
         es[0] = 0;
         for (int g = 1; g < 4; ++g) es[g] = std::max(es[g - 1], std::min(fb[g], mfcc::kNbin));
         es[4] = mfcc::kNbin;
-        int mx = 0, sum = 0, k0[4];
+        int mx = 0, sum = 0, k0[4], st[4];
         for (int g = 0; g < 4; ++g) {
           const int lo = std::min(es[g], fb[g]), hi = std::max(lb[g] + 1, es[g + 1]);
           k0[g] = std::min(lo, hi);
-          const int st = hi > lo ? (hi - lo + 3) / 4 : 0;
-          mx = std::max(mx, st);
-          sum += st;
+          st[g] = hi > lo ? (hi - lo + 3) / 4 : 0;
+          mx = std::max(mx, st[g]);
+          sum += st[g];
         }
         if (mx < best_max || (mx == best_max && sum < best_sum)) {
           best_max = mx; best_sum = sum;
           for (int g = 0; g < 5; ++g) { best_cut[g] = cut[g]; best_es[g] = es[g]; }
-          for (int g = 0; g < 4; ++g) best_k0[g] = k0[g];
+          for (int g = 0; g < 4; ++g) { best_k0[g] = k0[g]; best_steps[g] = st[g]; }
         }
       }
   if (best_max > mfcc::kMelSteps) {
     delete p;
     return fail(MFCC_ERR_UNSUPPORTED, "filterbank needs %d MFMA k-steps per wave, the kernel provides %d", best_max, mfcc::kMelSteps);
   }
-  memset(&p->map, 0, sizeof(p->map));
+  mfcc::PlanConst& pch = p->pc_host;
+  memset(&pch, 0, sizeof(pch));
+  mfcc::MelMap& pmap = pch.map;
   std::vector<float> melB((size_t)4 * mfcc::kMelSteps * 64, 0.f);
   for (int g = 0; g < 4; ++g) {
-    p->map.kstart[g] = std::min(best_k0[g], mfcc::kNbin - 1);
-    p->map.first_filter[g] = best_cut[g];
-    p->map.nfilt[g] = best_cut[g + 1] - best_cut[g];
+    pmap.kstart[g] = std::min(best_k0[g], mfcc::kNbin - 1);
+    pmap.first_filter[g] = best_cut[g];
+    pmap.nfilt[g] = best_cut[g + 1] - best_cut[g];
+    pch.mel_steps[g] = best_steps[g];
     for (int sidx = 0; sidx < mfcc::kMelSteps; ++sidx)
       for (int lane = 0; lane < 64; ++lane) {
-        const int k = p->map.kstart[g] + 4 * sidx + (lane >> 4), j = lane & 15;
+        const int k = pmap.kstart[g] + 4 * sidx + (lane >> 4), j = lane & 15;
         double w = 0.0;
         if (k < mfcc::kNbin) {
-          if (j < p->map.nfilt[g]) w = bank[(size_t)(best_cut[g] + j) * mfcc::kNbin + k];
+          if (j < pmap.nfilt[g]) w = bank[(size_t)(best_cut[g] + j) * mfcc::kNbin + k];
           else if (j == mfcc::kMelCols && k >= best_es[g] && k < best_es[g + 1]) w = 1.0;
         }
         melB[((size_t)g * mfcc::kMelSteps + sidx) * 64 + lane] = (float)(w * (double)p->spec_scale);
       }
   }
-  p->map.ndct = (nmel + 3) / 4;
+  pmap.ndct = (nmel + 3) / 4;
   const std::vector<double> dl = mfcc::dct_lifter(nmel, cfg->numcep, cfg->lift_factor, true);
   std::vector<float> dctB((size_t)mfcc::kDctSteps * 64, 0.f);
-  for (int sidx = 0; sidx < p->map.ndct; ++sidx)
+  for (int sidx = 0; sidx < pmap.ndct; ++sidx)
     for (int lane = 0; lane < 64; ++lane) {
       const int m = 4 * sidx + (lane >> 4), c = lane & 15;
       if (m < nmel && c < cfg->numcep) dctB[(size_t)sidx * 64 + lane] = (float)dl[(size_t)m * cfg->numcep + c];
@@ -231,6 +240,21 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
     mfcc_plan_destroy(p);
     return rc;
   }
+  pch.tw512 = p->tw512;
+  pch.melB = p->melB;
+  pch.dctB = p->dctB;
+  pch.window = p->window;
+  pch.nmel = nmel;
+  pch.numcep = cfg->numcep;
+  pch.pre_hi = cfg->use_preemph ? p->pre_hi : 0.f;
+  pch.pre_lo = cfg->use_preemph ? p->pre_lo : 0.f;
+  pch.spectrum = cfg->spectrum;
+  pch.floor_mel = cfg->floor_mel;
+  pch.spec_scale = p->spec_scale;
+  if ((rc = upload(std::vector<mfcc::PlanConst>(1, pch), &p->pc))) {
+    mfcc_plan_destroy(p);
+    return rc;
+  }
   *out = p;
   return MFCC_OK;
 }
@@ -241,6 +265,7 @@ int mfcc_plan_destroy(mfcc_plan* p) {
   (void)hipFree(p->melB);
   (void)hipFree(p->dctB);
   (void)hipFree(p->window);
+  (void)hipFree(p->pc);
   delete p;
   return MFCC_OK;
 }
@@ -371,21 +396,12 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   fp.tiles = layout->d_tiles;
   fp.out = out;
   fp.out_ld = out_ld;
-  fp.tw512 = plan->tw512;
   fp.total_elems = layout->total_samples;
-  fp.map = plan->map;
-  fp.melB = plan->melB;
-  fp.dctB = plan->dctB;
-  fp.window = plan->window;
-  fp.nmel = plan->cfg.num_bins;
-  fp.numcep = plan->cfg.numcep;
+  fp.pc = plan->pc;
   fp.audio_dtype = audio_dtype;
-  fp.use_preemph = plan->cfg.use_preemph;
-  fp.pre_hi = plan->pre_hi;
-  fp.pre_lo = plan->pre_lo;
-  fp.spectrum = plan->cfg.spectrum;
-  fp.floor_mel = plan->cfg.floor_mel;
-  fp.spec_scale = plan->spec_scale;
+#ifdef MFCC_DIAG
+  fp.dbg = g_dbg;
+#endif
 
   const dim3 grid((unsigned)layout->n_tiles), block(256);
   const size_t smem = mfcc::kSmemFloats * sizeof(float);

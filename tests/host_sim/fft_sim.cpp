@@ -20,30 +20,28 @@ int main(int argc, char** argv) {
     // ---- stage 1 : lane q = n2
     std::vector<float> T(512, 0.f);  // 256 complex, exchange buffer
     for (int q = 0; q < 16; ++q) {
-      float xr[16], xi[16];
+      mfcc::cf v[16];
       for (int n1 = 0; n1 < 16; ++n1) {
         const int n = 16 * n1 + q;
-        xr[n1] = x[2 * n];
-        xi[n1] = x[2 * n + 1];
+        v[n1] = mfcc::mk(x[2 * n], x[2 * n + 1]);
       }
-      mfcc::fft16(xr, xi);
+      mfcc::fft16(v);
       for (int k1 = 0; k1 < 16; ++k1) {
         const int m = (2 * q * k1) & 511;  // W256^(q k1) = W512^(2 q k1)
-        if (k1) mfcc::cmul(xr[k1], xi[k1], tw[2 * m], tw[2 * m + 1]);
+        if (k1) v[k1] = mfcc::cmul(v[k1], mfcc::mk(tw[2 * m], tw[2 * m + 1]));
         const int p = mfcc::xpose_index(k1, q);
-        T[2 * p] = xr[k1];
-        T[2 * p + 1] = xi[k1];
+        T[2 * p] = v[k1].x;
+        T[2 * p + 1] = v[k1].y;
       }
     }
     // ---- stage 2 : lane q = k1
-    float Zr[16][16], Zi[16][16];
+    mfcc::cf Z[16][16];
     for (int q = 0; q < 16; ++q) {
       for (int n2 = 0; n2 < 16; ++n2) {
         const int p = mfcc::xpose_index(q, n2);
-        Zr[q][n2] = T[2 * p];
-        Zi[q][n2] = T[2 * p + 1];
+        Z[q][n2] = mfcc::mk(T[2 * p], T[2 * p + 1]);
       }
-      mfcc::fft16(Zr[q], Zi[q]);
+      mfcc::fft16(Z[q]);
     }
     // ---- untangle
     std::vector<float> P(257, -1.f);
@@ -51,17 +49,17 @@ int main(int argc, char** argv) {
       const int pl = mfcc::partner_lane(q);
       for (int s = 0; s < 8; ++s) {
         const int k = q + 16 * s;
-        float br = Zr[pl][15 - s], bi = Zi[pl][15 - s];
-        if (q == 0) { br = Zr[0][(16 - s) & 15]; bi = Zi[0][(16 - s) & 15]; }
+        mfcc::cf b = Z[pl][15 - s];
+        if (q == 0) b = Z[0][(16 - s) & 15];
         float lo, hi;
-        mfcc::untangle_power(Zr[q][s], Zi[q][s], br, bi, tw[2 * k], tw[2 * k + 1], lo, hi);
+        mfcc::untangle_power(Z[q][s], b, mfcc::mk(tw[2 * k], tw[2 * k + 1]), lo, hi);
         if (P[k] != -1.f || P[256 - k] != -1.f) { printf("bin written twice: %d\n", k); return 2; }
         P[k] = lo;
         P[256 - k] = hi;
       }
       if (q == 0) {
         if (P[128] != -1.f) { printf("bin 128 written twice\n"); return 2; }
-        P[128] = 4.f * (Zr[0][8] * Zr[0][8] + Zi[0][8] * Zi[0][8]);
+        P[128] = 4.f * mfcc::norm2(Z[0][8]);
       }
     }
     // ---- reference
