@@ -398,25 +398,36 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       wave_sync();  // every lane of this wave has read its row before spectrum rows overwrite it
 
       float* const P = xbuf + fb * kSlot;
+      // Z[256-k] lives in the partner lane: fetch all eight partners and the eight untangle
+      // twiddles first, so that their latencies overlap instead of adding up
+      cf pb[8], pw[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) pb[s] = mk(lane_read(partner_addr, x[15 - s].x), lane_read(partner_addr, x[15 - s].y));
+#pragma unroll
+      for (int s = 0; s < 8; ++s) pw[s] = twq[15 + s];
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        cf b = mk(lane_read(partner_addr, x[15 - s].x), lane_read(partner_addr, x[15 - s].y));
-        if (q == 0) b = x[(16 - s) & 15];
+        if (q == 0) pb[s] = x[(16 - s) & 15];  // lane 0 pairs inside itself: Z[16 s] with Z[16 (16 - s)]
         float lo, hi;
 #ifndef MFCC_ABL_UNT
-        untangle_power(x[s], b, twq[15 + s], lo, hi);
+        untangle_power(x[s], pb[s], pw[s], lo, hi);
 #else
-        lo = x[s].x + b.x + twq[15 + s].x; hi = x[s].y + b.y + twq[15 + s].y;
+        lo = x[s].x + pb[s].x + pw[s].x; hi = x[s].y + pb[s].y + pw[s].y;
 #endif
-        if (mag) { lo = __builtin_amdgcn_sqrtf(lo); hi = __builtin_amdgcn_sqrtf(hi); }
         P[q + 16 * s] = lo;
         P[256 - q - 16 * s] = hi;
       }
       if (q == 0) {  // bin 128 pairs with itself: X[128] = conj Z[128]
-        float m = 4.f * norm2(x[8]);
-        if (mag) m = __builtin_amdgcn_sqrtf(m);
-        P[128] = m;
+        P[128] = 4.f * norm2(x[8]);
         P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-step
+      }
+      if (mag) {
+        // magnitude spectrum (mfcc-self15.py:234): a pass of its own over the row, so that the
+        // power path does not pay for the square roots
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) P[q + 16 * s] = __builtin_amdgcn_sqrtf(P[q + 16 * s]);
+        if (q == 0) P[256] = __builtin_amdgcn_sqrtf(P[256]);
       }
       if (OUT != kOutSpec && OUT != kOutLogspec) {
         // the frame registers are dead: fetch the filterbank operands now, they arrive while

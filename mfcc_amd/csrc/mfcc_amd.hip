@@ -404,7 +404,10 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
 #endif
 
   const dim3 grid((unsigned)layout->n_tiles), block(256);
-  const size_t smem = mfcc::kSmemFloats * sizeof(float);
+#ifndef MFCC_EXTRA_SMEM
+#define MFCC_EXTRA_SMEM 0  // occupancy experiments only
+#endif
+  const size_t smem = mfcc::kSmemFloats * sizeof(float) + MFCC_EXTRA_SMEM;
   hipStream_t st = (hipStream_t)stream;
   const bool c13 = plan->cfg.numcep == 13;
   switch (out_kind) {
