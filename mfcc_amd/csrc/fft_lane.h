@@ -119,9 +119,13 @@ MFCC_HD void radix4(cf& a0, cf& a1, cf& a2, cf& a3) {
 
 // 16-point forward DFT, natural order in and out, all indices compile-time.
 // x[n], n = 4a + b;  X[c + 4d] = sum_b W4^(bd) W16^(bc) sum_a x[4a+b] W4^(ac).
-MFCC_HD void fft16(cf (&x)[16]) {
+// Split in three parts so that a caller can slot independent work (matrix-core
+// instructions of another product) between them; fft16 = a, b, c.
+MFCC_HD void fft16_a(cf (&x)[16]) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) radix4(x[b], x[4 + b], x[8 + b], x[12 + b]);
+}
+MFCC_HD void fft16_b(cf (&x)[16]) {
   // after the first pass x[4c + b] holds Y_b[c]; twiddle by W16^(bc), W16^m = (cos, -sin)(2 pi m / 16)
   x[4 + 1] = cmulk(x[4 + 1], mk(kC1, -kS1));     // b=1 c=1  m=1
   x[8 + 1] = cmulk(x[8 + 1], mk(kR2, -kR2));     // b=1 c=2  m=2
@@ -132,6 +136,8 @@ MFCC_HD void fft16(cf (&x)[16]) {
   x[4 + 3] = cmulk(x[4 + 3], mk(kS1, -kC1));     // b=3 c=1  m=3
   x[8 + 3] = cmulk(x[8 + 3], mk(-kR2, -kR2));    // b=3 c=2  m=6
   x[12 + 3] = cmulk(x[12 + 3], mk(-kC1, kS1));   // b=3 c=3  m=9
+}
+MFCC_HD void fft16_c(cf (&x)[16]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) radix4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
   // x[4c + d] now holds X[c + 4d]: transpose the 4x4 index grid (register renaming only)
@@ -143,6 +149,11 @@ MFCC_HD void fft16(cf (&x)[16]) {
       x[4 * c + d] = x[4 * d + c];
       x[4 * d + c] = t;
     }
+}
+MFCC_HD void fft16(cf (&x)[16]) {
+  fft16_a(x);
+  fft16_b(x);
+  fft16_c(x);
 }
 
 // Position (in complex elements) of Y[k1][n2] inside one frame's 256-element exchange

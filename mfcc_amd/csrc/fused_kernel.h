@@ -133,6 +133,11 @@ enum : int { kOutMfcc39 = 0, kOutStatic = 1, kOutLogmel = 2, kOutSpec = 3, kOutL
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Pointers read out of PlanConst are generic to the compiler; the tables live in device
+// memory, and saying so turns flat loads (which also tie up the LDS counter) into global ones.
+typedef const float __attribute__((address_space(1))) * gfloat_ptr;
+__device__ __forceinline__ gfloat_ptr as_global(const float* p) { return (gfloat_ptr)(uintptr_t)p; }
+
 __device__ __forceinline__ void wave_sync() {
   // LDS operations of one wave execute in program order; this only stops the compiler
   // from moving LDS accesses across the exchange point.
@@ -229,11 +234,21 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int
       for (int j = 0; j < 4; ++j) x[1 + j] = __uint_as_float(w[j]);
     }
     float y[CE];
+    // y[n] = x[n] - c x[n-1] (mfcc-self5.py:68).  int16 input: numpy works in float64, matched
+    // by a two-term coefficient and fused multiply-adds, two samples per packed instruction;
+    // float32 input: numpy works in float32 with two roundings.
+    if (sizeof(T) == 2) {
+      const cf nhi = mk(-pre_hi, -pre_hi), nlo = mk(-pre_lo, -pre_lo);
 #pragma unroll
-    for (int j = 0; j < CE; ++j) {
-      // y[n] = x[n] - c x[n-1]; for float32 input numpy evaluates this in float32 with two roundings
-      if (sizeof(T) == 2) y[j] = fmaf(-pre_lo, x[j], fmaf(-pre_hi, x[j], x[j + 1]));
-      else y[j] = __fsub_rn(x[j + 1], __fmul_rn(pre_hi, x[j]));
+      for (int j = 0; j < CE; j += 2) {
+        const cf x0 = mk(x[j], x[j + 1]), x1 = mk(x[j + 1], x[j + 2]);
+        const cf r = __builtin_elementwise_fma(nlo, x0, __builtin_elementwise_fma(nhi, x0, x1));
+        y[j] = r.x;
+        y[j + 1] = r.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CE; ++j) y[j] = __fsub_rn(x[j + 1], __fmul_rn(pre_hi, x[j]));
     }
     if (!interior) {
 #pragma unroll
@@ -282,21 +297,21 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const out_t0 = p.out + (f_off + t0) * p.out_ld;  // row t0 of this tile; 32-bit offsets from here
   const float pre_hi = pc->pre_hi, pre_lo = pc->pre_lo;
   const bool mag = pc->spectrum != 0;
-  const float* const window = pc->window;
+  const gfloat_ptr window = as_global(pc->window);
   // this wave's share of the filterbank product
   const int mel_k0 = pc->map.kstart[wave], mel_nf = pc->map.nfilt[wave], mel_ff = pc->map.first_filter[wave];
   const int mel_ns = pc->mel_steps[wave];
-  const float* const melB = pc->melB + (wave * kMelSteps) * 64 + lane;
+  const gfloat_ptr melB = as_global(pc->melB) + (wave * kMelSteps) * 64 + lane;
 
   // Twiddles per lane index q: stage 1 uses W256^(q k1) = W512^(2 q k1), k1 = 1..15, the
   // untangle W512^(q + 16 s), s = 0..7.  They live in LDS (row q, 23 complex values) and are
   // read when needed: 46 registers per lane would cost a wave of occupancy.
   {
-    const float* tw = pc->tw512;
+    const gfloat_ptr tw = as_global(pc->tw512);
     for (int i = tid; i < 16 * 23; i += 256) {
       const int qq = i / 23, k = i - qq * 23;
       const int m = k < 15 ? (2 * qq * (k + 1)) & 511 : qq + 16 * (k - 15);
-      *(cf*)(twl + qq * kTwPitch + 2 * k) = *(const cf*)(tw + 2 * m);
+      *(cf*)(twl + qq * kTwPitch + 2 * k) = mk(tw[2 * m], tw[2 * m + 1]);
     }
   }
   const cf* const twq = (const cf*)(twl + q * kTwPitch);
@@ -318,7 +333,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   // columns nmel.. of the ln-mel rows are multiplied by zero DCT weights: keep them finite
   for (int i = tid; i < kLbufFloats; i += 256) lbuf[i] = 0.f;
   {
-    const float* src = pc->dctB;
+    const gfloat_ptr src = as_global(pc->dctB);
     for (int i = tid; i < kDctBFloats; i += 256) dctb[i] = src[i];
   }
   int delta = stage_st(s_lo);
@@ -365,7 +380,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       if (window) {
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1)
-          if (2 * (16 * n1) < kFrameSize) x[n1] = x[n1] * *(const cf*)(window + 2 * (16 * n1 + q));
+          if (2 * (16 * n1) < kFrameSize) x[n1] = x[n1] * mk(window[2 * (16 * n1 + q)], window[2 * (16 * n1 + q) + 1]);
       }
 #ifndef MFCC_ABL_FFT
       fft16(x);
@@ -524,9 +539,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     }
 
     // ---- DCT-II * lifter on the matrix cores, c0 := ln E  (mfcc-self5.py:136-167) ----------
-    // Every wave forms the whole 16 x 16 product (7 MFMAs) and stores the 4 rows held by its
-    // own lane group, so no wave waits for another.  lbuf/epbuf are rewritten only after the
-    // next spectrum barrier.
+    // Every wave forms the whole 16 x 16 product (7 MFMAs) and stores a quarter of it, so no
+    // wave waits for another.  lbuf/epbuf are rewritten only after the next spectrum barrier.
 #ifndef MFCC_ABL_DCT
     {
       const int nd = pc->map.ndct;
@@ -535,22 +549,19 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
       for (int s = 0; s < kDctSteps; ++s)
         if (s < nd) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Lr[4 * s], dctb[s * 64 + lane], acc, 0, 0, 0);
-      if (g4 == wave && q < ncep) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 4 * g4 + r;
-          const int t = tb + i;
-          float v = acc[r];
-          if (q == 0) {  // mfcc-self5.py:130-132 and :164
-            float e = (epbuf[i] + epbuf[16 + i]) + (epbuf[32 + i] + epbuf[48 + i]);
-            if (e == 0.f) e = kEps64;
-            v = fast_ln(e);
-          }
-          if (t < s_hi) {
-            if (t >= t0 && t < t0 + nt) out_t0[(t - t0) * ld + q] = v;
-            else hbuf[(t < t0 ? t - s_lo : kHalo + t - (t0 + nt)) * kMaxCep + q] = v;
-          }
-        }
+      // The four waves hold the same product: wave w stores row 4*g4 + w of every lane group
+      // (one store instruction with all four groups active).  c0 := ln E, floored at the
+      // float64 epsilon (mfcc-self5.py:130-132 and :164).
+      const int i = 4 * g4 + wave;
+      const int t = tb + i;
+      float v = wave == 0 ? acc[0] : wave == 1 ? acc[1] : wave == 2 ? acc[2] : acc[3];
+      float e = (epbuf[i] + epbuf[16 + i]) + (epbuf[32 + i] + epbuf[48 + i]);
+      if (e == 0.f) e = kEps64;
+      e = fast_ln(e);
+      if (q == 0) v = e;
+      if (q < ncep) {
+        if ((unsigned)(t - t0) < (unsigned)nt) out_t0[(t - t0) * ld + q] = v;
+        else if (t < s_hi) hbuf[(t < t0 ? t - s_lo : kHalo + t - (t0 + nt)) * kMaxCep + q] = v;
       }
     }
 #endif
@@ -577,52 +588,69 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   if (OUT == kOutMfcc39) {
 #endif
     // ---- epilogue: statics back from L2, delta, delta-delta, remaining columns out ----------
+    // Thread (c, chunk) = (tid & 15, tid >> 4) owns column c of a run of consecutive rows and
+    // slides a 5-row window down it: one LDS read per row and no index division.
     __syncthreads();  // all static columns of the tile are written and visible to this workgroup
-    float* const sb = xbuf;                             // [(s_hi - s_lo)][ncep]
+    const int ns = s_hi - s_lo;
     const int d_lo = max(0, t0 - 2), d_hi = min(nframes, t0 + nt + 2);
-    float* const db = xbuf + (s_hi - s_lo) * ncep;      // [(d_hi - d_lo)][ncep]
-    const int last = nframes - 1;
-    for (int idx = tid; idx < (s_hi - s_lo) * ncep; idx += 256) {
-      const int r = idx / ncep, c = idx - r * ncep;
-      const int t = s_lo + r;
-      float v;
-      if (t < t0) v = hbuf[r * kMaxCep + c];
-      else if (t >= t0 + nt) v = hbuf[(kHalo + t - (t0 + nt)) * kMaxCep + c];
-      else v = out_t0[(t - t0) * ld + c];
-      sb[idx] = v;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < (d_hi - d_lo) * ncep; idx += 256) {
-      const int r = idx / ncep, c = idx - r * ncep;
-      const int t = d_lo + r;
-      const float a = sb[(max(t - 2, 0) - s_lo) * ncep + c];
-      const float b = sb[(max(t - 1, 0) - s_lo) * ncep + c];
-      const float m = sb[(t - s_lo) * ncep + c];
-      const float d = sb[(min(t + 1, last) - s_lo) * ncep + c];
-      const float e = sb[(min(t + 2, last) - s_lo) * ncep + c];
-      // (-2a - b + 0m + d + 2e) / 10; the zero-weight centre tap keeps NaN propagation
-      // identical to np.dot over the 5-row window (mfcc-self5.py:177-178)
-      db[idx] = (2.f * (e - a) + (d - b) + 0.f * m) * 0.1f;
-    }
-    __syncthreads();
-    const int width = 2 * ncep;
-    for (int idx = tid; idx < nt * width; idx += 256) {
-      const int r = idx / width, c = idx - r * width;
-      const int t = t0 + r;
-      float v;
-      if (c < ncep) {
-        v = db[(t - d_lo) * ncep + c];
-      } else {
-        const int cc = c - ncep;
-        const float a = db[(max(t - 2, 0) - d_lo) * ncep + cc];
-        const float b = db[(max(t - 1, 0) - d_lo) * ncep + cc];
-        const float m = db[(t - d_lo) * ncep + cc];
-        const float d = db[(min(t + 1, last) - d_lo) * ncep + cc];
-        const float e = db[(min(t + 2, last) - d_lo) * ncep + cc];
-        v = (2.f * (e - a) + (d - b) + 0.f * m) * 0.1f;
+    float* const sb = xbuf;              // statics of rows s_lo .. s_hi-1, [ns][ncep]
+    float* const db = xbuf + ns * ncep;  // deltas  of rows d_lo .. d_hi-1
+    const int c = tid & 15, chunk = tid >> 4;
+    const bool col = c < ncep;
+    if (col) {
+      // halo rows come from LDS, the tile's own rows from the output (L2-hot)
+      if (chunk < kHalo) {
+        if (chunk < t0 - s_lo) sb[chunk * ncep + c] = hbuf[chunk * kMaxCep + c];
+      } else if (chunk < 2 * kHalo) {
+        const int k = chunk - kHalo;
+        if (k < s_hi - (t0 + nt)) sb[(t0 - s_lo + nt + k) * ncep + c] = hbuf[chunk * kMaxCep + c];
       }
-      out_t0[r * ld + ncep + c] = v;
+      const int R = (nt + 15) >> 4;
+      const int i0 = chunk * R, i1 = min(nt, i0 + R);
+      float* const dst = sb + (t0 - s_lo) * ncep + c;
+      const float* const src = out_t0 + c;
+      for (int i = i0; i < i1; i += 4) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = src[min(i + j, i1 - 1) * ld];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (i + j < i1) dst[(i + j) * ncep] = v[j];
+      }
     }
+    __syncthreads();
+    // (-2a - b + 0m + d + 2e) / 10 over rows clamped to the utterance (mfcc-self5.py:174-178);
+    // the zero-weight centre tap keeps NaN propagation identical to np.dot over the window.
+    // src holds rows lo..hi of the input; rows [t_lo, t_hi) are produced, written to the output
+    // column block at out_col where they belong to the tile, and kept in LDS if keep != nullptr.
+    auto delta_pass = [&](const float* src, int lo, int hi, int t_lo, int t_hi, float* keep, int out_col) {
+      const int R = (t_hi - t_lo + 15) >> 4;
+      const int ta = t_lo + chunk * R, tz = min(t_hi, ta + R);
+      if (!col || ta >= tz) return;
+      const float* const S = src + c - lo * ncep;  // S[t * ncep] = value of row t
+      float a = S[max(ta - 2, lo) * ncep], b = S[max(ta - 1, lo) * ncep], m = S[ta * ncep], d = S[min(ta + 1, hi) * ncep];
+      for (int t = ta; t < tz; t += 4) {
+        float e[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = S[min(t + 2 + j, hi) * ncep];
+        v[0] = (2.f * (e[0] - a) + (d - b) + 0.f * m) * 0.1f;
+        v[1] = (2.f * (e[1] - b) + (e[0] - m) + 0.f * d) * 0.1f;
+        v[2] = (2.f * (e[2] - m) + (e[1] - d) + 0.f * e[0]) * 0.1f;
+        v[3] = (2.f * (e[3] - d) + (e[2] - e[0]) + 0.f * e[1]) * 0.1f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int tt = t + j;
+          if (tt < tz) {
+            if (keep) keep[(tt - t_lo) * ncep + c] = v[j];
+            if (tt >= t0 && tt < t0 + nt) out_t0[(tt - t0) * ld + out_col + c] = v[j];
+          }
+        }
+        a = e[0]; b = e[1]; m = e[2]; d = e[3];
+      }
+    };
+    delta_pass(sb, s_lo, s_hi - 1, d_lo, d_hi, db, ncep);
+    __syncthreads();
+    delta_pass(db, d_lo, d_hi - 1, t0, t0 + nt, nullptr, 2 * ncep);
   }
 #ifdef MFCC_DIAG
   {
