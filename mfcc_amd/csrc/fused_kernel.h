@@ -45,11 +45,12 @@ constexpr int kMaxCep = 16;
 constexpr int kMaxMel = 40;       // "26-40 Mel bins" (mfcc-self5.py:23); bounds the LDS tables
 constexpr int kStage = (kBatch - 1) * kFrameStep + kFrameSize;  // 2800 samples per batch
 constexpr int kMelCols = 15;      // filter columns per wave; column 15 carries the wave's energy partial
-constexpr int kMelSteps = 24;     // MFMA k-steps (4 bins each) per wave, upper bound
+constexpr int kMelSteps = 24;     // MFMA k-steps (4 bins each) every wave runs
 constexpr int kDctSteps = (kMaxMel + 3) / 4;
 
 // LDS carve (floats).
 constexpr int kSlot = 514;                           // spectrum row of frame f starts at f*514
+constexpr int kRowPad = 260;                         // bins 0..256 plus zeros up to a multiple of 4
 constexpr int kXbufFloats = kBatch * kSlot;          // exchange buffers (fb*512) / spectrum rows; epilogue scratch
 constexpr int kAbufFloats = 2808;                    // staged audio: kStage + up to 7 alignment samples, whole chunks
 constexpr int kLogPitch = 49;                        // ln-mel row of a frame (odd pitch: conflict-free column reads)
@@ -108,14 +109,13 @@ struct PlanConst {
 
 struct FusedParams {
   const void* audio;
-  int64_t total_elems;        // elements in `audio` (bounds the 16-byte staging loads)
+  int64_t total_elems;        // elements in `audio`, >= 1 (bounds the 16-byte staging loads)
   const int64_t* sample_off;  // [n_utts + 1]
   const int64_t* frame_off;   // [n_utts + 1]
   const Tile* tiles;
   float* out;
   int64_t out_ld;
   const PlanConst* pc;
-  int32_t audio_dtype;        // 0 = int16, 1 = float32
 #ifdef MFCC_DIAG
   unsigned long long* dbg;    // [n_tiles][4 waves][8] cycle sums
 #endif
@@ -166,40 +166,37 @@ struct StageRegs {
   int delta;
 };
 
+// stage_load has no branch at all: addresses are clamped instead.  An aligned 16-byte chunk
+// that holds at least one byte of the buffer cannot fault, so the only chunks to avoid are
+// those entirely behind the buffer end (they are pulled back to the last valid chunk) and a
+// thread without a chunk of its own repeats the batch's last chunk (same cache line, no extra
+// HBM traffic).  Whatever such loads return lies outside the utterance and is overwritten with
+// zeros by stage_store.  Being branch-free matters: the loads stay in one basic block with the
+// matrix-core section that follows, which lets the compiler wait for the filterbank operands
+// without also waiting for these (younger, HBM-latency) loads.
 template <typename T>
-__device__ __forceinline__ void stage_load(const T* utt, int64_t before, int64_t after, StageRegs& r, int tb, int tid) {
-  // utt = first sample of the utterance; `before` / `after` = elements of the audio buffer in
-  // front of it / from it to the end of the buffer (bounds for the aligned loads)
+__device__ __forceinline__ void stage_load(const T* buf, int64_t total, int64_t s_off, StageRegs& r, int tb, int tid) {
+  // buf/total = the whole audio buffer (total >= 1), s_off = first sample of the utterance
   constexpr int CE = 16 / (int)sizeof(T);  // elements per chunk
   constexpr int NR = sizeof(T) == 2 ? 2 : 3;
-  const T* b0 = utt + (int64_t)tb * kFrameStep;  // first sample of the batch
+  constexpr int64_t kBig = 1 << 24;
+  const T* const b0 = buf + s_off + (int64_t)tb * kFrameStep;  // first sample of the batch
   const int delta = (int)(((uintptr_t)b0 & 15) / sizeof(T));
-  const T* a0 = b0 - delta;                      // aligned chunk 0 (pointer arithmetic keeps it a global pointer)
-  constexpr int kBig = 1 << 20;
-  const int64_t lo64 = -(before + (int64_t)tb * kFrameStep - delta);
-  const int64_t hi64 = after - (int64_t)tb * kFrameStep + delta;
-  const int e_lo = lo64 < -kBig ? -kBig : (int)lo64;  // chunk-relative element range inside the audio buffer
-  const int e_hi = hi64 > kBig ? kBig : (int)hi64;
-  const int nchunk = (delta + kStage + CE - 1) / CE;
+  const T* const a0 = b0 - delta;                               // aligned chunk 0
+  const T* const last = buf + (total - 1);                      // last element of the buffer
+  const T* const hi_chunk = last - (((uintptr_t)last & 15) / sizeof(T));
+  const T* const a0c = a0 < hi_chunk ? a0 : hi_chunk;
+  const T* const p0 = a0c - 1;                                  // element in front of chunk 0 (offset-only use)
+  const int64_t hi64 = hi_chunk - a0c, hip64 = last - p0;
+  const unsigned hi_el = (unsigned)(hi64 < kBig ? hi64 : kBig), hip_el = (unsigned)(hip64 < kBig ? hip64 : kBig);
+  const unsigned lop_el = a0c > buf ? 0u : (unsigned)(buf - a0c) + 1u;  // first offset from p0 inside the buffer
+  const unsigned nchunk = (delta + kStage + CE - 1) / CE;
   r.delta = delta;
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
-    const int c = tid + 256 * k;
-    const int e0 = c * CE;
-    r.raw[k] = make_uint4(0, 0, 0, 0);
-    r.prev[k] = 0.f;
-    if (c < nchunk) {
-      if (e0 > e_lo && e0 + CE <= e_hi) {  // chunk and its predecessor sample lie inside the buffer
-        r.raw[k] = *(const uint4*)(a0 + e0);
-        r.prev[k] = (float)a0[e0 - 1];
-      } else {  // chunk straddles an end of the buffer: element-wise, zero outside
-        T tmp[CE];
-#pragma unroll
-        for (int j = 0; j < CE; ++j) tmp[j] = (e0 + j >= e_lo && e0 + j < e_hi) ? a0[e0 + j] : (T)0;
-        r.raw[k] = *(const uint4*)tmp;
-        if (e0 - 1 >= e_lo && e0 - 1 < e_hi) r.prev[k] = (float)a0[e0 - 1];
-      }
-    }
+    const unsigned c = min((unsigned)(tid + 256 * k), nchunk - 1);
+    r.raw[k] = *(const uint4*)(a0c + min(c * CE, hi_el));
+    r.prev[k] = (float)p0[min(max(c * CE, lop_el), hip_el)];
   }
 }
 
@@ -264,7 +261,8 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int
 }
 
 // NCEP > 0 fixes numcep at compile time (cheap index arithmetic in the epilogue); 0 = runtime.
-template <int OUT, int NCEP>
+// T is the sample type of the audio buffer (int16_t or float).
+template <int OUT, int NCEP, typename T>
 __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(128))) float smem[];
   float* const xbuf = smem;
@@ -300,7 +298,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const gfloat_ptr window = as_global(pc->window);
   // this wave's share of the filterbank product
   const int mel_k0 = pc->map.kstart[wave], mel_nf = pc->map.nfilt[wave], mel_ff = pc->map.first_filter[wave];
-  const int mel_ns = pc->mel_steps[wave];
   const gfloat_ptr melB = as_global(pc->melB) + (wave * kMelSteps) * 64 + lane;
 
   // Twiddles per lane index q: stage 1 uses W256^(q k1) = W512^(2 q k1), k1 = 1..15, the
@@ -318,16 +315,13 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const int partner_addr = ((lane & 48) | partner_lane(q)) << 2;
 
   StageRegs sr;
-  const bool i16 = p.audio_dtype == 0;
-  auto stage_ld = [&](int tb) {
-    if (i16) stage_load<int16_t>((const int16_t*)p.audio + s_off, s_off, p.total_elems - s_off, sr, tb, tid);
-    else stage_load<float>((const float*)p.audio + s_off, s_off, p.total_elems - s_off, sr, tb, tid);
-  };
+  auto stage_ld = [&](int tb) { stage_load<T>((const T*)p.audio, p.total_elems, s_off, sr, tb, tid); };
   auto stage_st = [&](int tb) -> int {
-    if (i16) stage_store<int16_t>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
-    else stage_store<float>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
+    stage_store<T>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
     return sr.delta;
   };
+  // floor of the mel energies: 0 = none (ln 0 = -inf as the reference, mfcc-self5.py:125-127)
+  const float mel_floor = pc->floor_mel != 0 ? kEps64 : 0.f;
 
   stage_ld(s_lo);
   // columns nmel.. of the ln-mel rows are multiplied by zero DCT weights: keep them finite
@@ -412,29 +406,37 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #endif
       wave_sync();  // every lane of this wave has read its row before spectrum rows overwrite it
 
+      if (OUT != kOutSpec && OUT != kOutLogspec) {
+        // fetch the filterbank operands of this wave now (L2 latency ~ the untangle below)
+#pragma unroll
+        for (int s = 0; s < kMelSteps; ++s) bv[s] = melB[s * 64];
+      }
       float* const P = xbuf + fb * kSlot;
-      // Z[256-k] lives in the partner lane: fetch all eight partners and the eight untangle
-      // twiddles first, so that their latencies overlap instead of adding up
-      cf pb[8], pw[8];
+      // Z[256-k] lives in the partner lane: fetch four partners and four untangle twiddles at
+      // a time, so that their latencies overlap instead of adding up
 #pragma unroll
-      for (int s = 0; s < 8; ++s) pb[s] = mk(lane_read(partner_addr, x[15 - s].x), lane_read(partner_addr, x[15 - s].y));
+      for (int h = 0; h < 8; h += 4) {
+        cf pb[4], pw[4];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) pw[s] = twq[15 + s];
+        for (int s = 0; s < 4; ++s) pb[s] = mk(lane_read(partner_addr, x[15 - h - s].x), lane_read(partner_addr, x[15 - h - s].y));
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        if (q == 0) pb[s] = x[(16 - s) & 15];  // lane 0 pairs inside itself: Z[16 s] with Z[16 (16 - s)]
-        float lo, hi;
+        for (int s = 0; s < 4; ++s) pw[s] = twq[15 + h + s];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (q == 0) pb[s] = x[(16 - h - s) & 15];  // lane 0 pairs inside itself: Z[16 s] with Z[16 (16 - s)]
+          float lo, hi;
 #ifndef MFCC_ABL_UNT
-        untangle_power(x[s], pb[s], pw[s], lo, hi);
+          untangle_power(x[h + s], pb[s], pw[s], lo, hi);
 #else
-        lo = x[s].x + pb[s].x + pw[s].x; hi = x[s].y + pb[s].y + pw[s].y;
+          lo = x[h + s].x + pb[s].x + pw[s].x; hi = x[h + s].y + pb[s].y + pw[s].y;
 #endif
-        P[q + 16 * s] = lo;
-        P[256 - q - 16 * s] = hi;
+          P[q + 16 * (h + s)] = lo;
+          P[256 - q - 16 * (h + s)] = hi;
+        }
       }
       if (q == 0) {  // bin 128 pairs with itself: X[128] = conj Z[128]
         P[128] = 4.f * norm2(x[8]);
-        P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-step
+        P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-steps
       }
       if (mag) {
         // magnitude spectrum (mfcc-self15.py:234): a pass of its own over the row, so that the
@@ -443,12 +445,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
         for (int s = 0; s < 16; ++s) P[q + 16 * s] = __builtin_amdgcn_sqrtf(P[q + 16 * s]);
         if (q == 0) P[256] = __builtin_amdgcn_sqrtf(P[256]);
-      }
-      if (OUT != kOutSpec && OUT != kOutLogspec) {
-        // the frame registers are dead: fetch the filterbank operands now, they arrive while
-        // this wave waits at the barrier
-#pragma unroll
-        for (int s = 0; s < kMelSteps; ++s) bv[s] = melB[s * 64];
       }
     }
     MFCC_STAMP(tb1);
@@ -459,7 +455,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     if (OUT == kOutSpec || OUT == kOutLogspec) {
       const int nvalid = min(kBatch, s_hi - tb);
       const float scale = pc->spec_scale;
-      if (more) stage_ld(tb + kBatch);
+      stage_ld(tb + kBatch);
       for (int idx = tid; idx < nvalid * kNbin; idx += 256) {
         const int f = idx / kNbin, k = idx - f * kNbin;
         float v = xbuf[f * kSlot + k] * scale;
@@ -473,22 +469,20 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 
     // ---- mel filterbank on the matrix cores: D[frame][col] = sum_bin P[frame][bin] W[bin][col]
 #ifndef MFCC_ABL_STAGE
-    if (more) stage_ld(tb + kBatch);  // HBM latency runs under the MFMAs below
+    stage_ld(tb + kBatch);  // unconditional and branch-free; HBM latency runs under the MFMAs below
 #endif
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
       const float* Prow = xbuf + q * kSlot + g4 + mel_k0;
 #ifndef MFCC_ABL_MEL
+      // All kMelSteps k-steps run unconditionally (no branch between them, so the operand reads
+      // are issued ahead of the chain); steps a wave does not need carry zero weights, and the
+      // plan keeps kstart + 4*kMelSteps inside the zero-padded row.  Two accumulators: the MFMA
+      // dependency chain is half as long.
 #pragma unroll
-      for (int s = 0; s < kMelSteps; s += 4) {
-        // two accumulators: the MFMA dependency chain is half as long.  k-steps past the wave's
-        // range (up to 3 per wave) have zero weights and read finite leftovers of the buffer.
-        if (s < mel_ns) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s], bv[s], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s + 4], bv[s + 1], acc2, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s + 8], bv[s + 2], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s + 12], bv[s + 3], acc2, 0, 0, 0);
-        }
+      for (int s = 0; s < kMelSteps; s += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s], bv[s], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s + 4], bv[s + 1], acc2, 0, 0, 0);
       }
       acc += acc2;
 #else
@@ -497,11 +491,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // lane holds rows 4*g4 + r of column q: filters take ln at once (mfcc-self5.py:125-127,
       // unfloored by default: ln 0 = -inf), column 15 is this wave's share of the energy sum
       if (q < mel_nf) {
-        const bool fl = pc->floor_mel != 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[r];
-          if (fl && v == 0.f) v = kEps64;
+          if (v == 0.f) v = mel_floor;
 #ifndef MFCC_ABL_LOG
           lbuf[(4 * g4 + r) * kLogPitch + mel_ff + q] = fast_ln(v);
 #else

@@ -205,7 +205,8 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   mfcc::MelMap& pmap = pch.map;
   std::vector<float> melB((size_t)4 * mfcc::kMelSteps * 64, 0.f);
   for (int g = 0; g < 4; ++g) {
-    pmap.kstart[g] = std::min(best_k0[g], mfcc::kNbin - 1);
+    // every wave runs all kMelSteps k-steps: keep them inside the zero-padded spectrum row
+    pmap.kstart[g] = std::min(best_k0[g], mfcc::kRowPad - 4 * mfcc::kMelSteps);
     pmap.first_filter[g] = best_cut[g];
     pmap.nfilt[g] = best_cut[g + 1] - best_cut[g];
     pch.mel_steps[g] = best_steps[g];
@@ -387,7 +388,7 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   if (width < 0) return width;
   if (out_ld < width) return fail(MFCC_ERR_INVALID, "out_ld=%lld < row width %d", (long long)out_ld, width);
   if (layout->n_utts == 0) return MFCC_OK;
-  if (!audio || !out) return fail(MFCC_ERR_INVALID, "mfcc_forward: null device pointer");
+  if (!out || (!audio && layout->total_samples > 0)) return fail(MFCC_ERR_INVALID, "mfcc_forward: null device pointer");
 
   mfcc::FusedParams fp;
   fp.audio = audio;
@@ -397,8 +398,13 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   fp.out = out;
   fp.out_ld = out_ld;
   fp.total_elems = layout->total_samples;
+  if (layout->total_samples == 0) {
+    // only empty utterances (one all-zero frame each): the kernel's clamped staging loads still
+    // need 16 readable bytes, which the layout's own offset array provides
+    fp.audio = layout->d_sample_off;
+    fp.total_elems = 1;
+  }
   fp.pc = plan->pc;
-  fp.audio_dtype = audio_dtype;
 #ifdef MFCC_DIAG
   fp.dbg = g_dbg;
 #endif
@@ -410,19 +416,26 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   const size_t smem = mfcc::kSmemFloats * sizeof(float) + MFCC_EXTRA_SMEM;
   hipStream_t st = (hipStream_t)stream;
   const bool c13 = plan->cfg.numcep == 13;
+  const bool i16 = audio_dtype == MFCC_AUDIO_I16;
+#define MFCC_LAUNCH(OUT, NCEP)                                                                               \
+  do {                                                                                                       \
+    if (i16) hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, int16_t>), grid, block, smem, st, fp);        \
+    else hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, float>), grid, block, smem, st, fp);              \
+  } while (0)
   switch (out_kind) {
     case MFCC_OUT_MFCC39:
-      if (c13) hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutMfcc39, 13>), grid, block, smem, st, fp);
-      else hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutMfcc39, 0>), grid, block, smem, st, fp);
+      if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39, 13);
+      else MFCC_LAUNCH(mfcc::kOutMfcc39, 0);
       break;
     case MFCC_OUT_STATIC:
-      if (c13) hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutStatic, 13>), grid, block, smem, st, fp);
-      else hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutStatic, 0>), grid, block, smem, st, fp);
+      if (c13) MFCC_LAUNCH(mfcc::kOutStatic, 13);
+      else MFCC_LAUNCH(mfcc::kOutStatic, 0);
       break;
-    case MFCC_OUT_LOGMEL: hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutLogmel, 0>), grid, block, smem, st, fp); break;
-    case MFCC_OUT_SPEC: hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutSpec, 0>), grid, block, smem, st, fp); break;
-    case MFCC_OUT_LOGSPEC: hipLaunchKernelGGL((mfcc::fused_kernel<mfcc::kOutLogspec, 0>), grid, block, smem, st, fp); break;
+    case MFCC_OUT_LOGMEL: MFCC_LAUNCH(mfcc::kOutLogmel, 0); break;
+    case MFCC_OUT_SPEC: MFCC_LAUNCH(mfcc::kOutSpec, 0); break;
+    case MFCC_OUT_LOGSPEC: MFCC_LAUNCH(mfcc::kOutLogspec, 0); break;
   }
+#undef MFCC_LAUNCH
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
 }
