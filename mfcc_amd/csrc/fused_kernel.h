@@ -320,6 +320,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     stage_store<T>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
     return sr.delta;
   };
+  const int nd = pc->map.ndct;
   // floor of the mel energies: 0 = none (ln 0 = -inf as the reference, mfcc-self5.py:125-127)
   const float mel_floor = pc->floor_mel != 0 ? kEps64 : 0.f;
 
@@ -372,9 +373,12 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         }
       }
       if (window) {
+        // all window loads first (they hit L1/L2), then the products: one wait instead of 13
+        cf wv[(kFrameSize + 31) / 32];
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1)
-          if (2 * (16 * n1) < kFrameSize) x[n1] = x[n1] * mk(window[2 * (16 * n1 + q)], window[2 * (16 * n1 + q) + 1]);
+        for (int n1 = 0; n1 < (kFrameSize + 31) / 32; ++n1) wv[n1] = mk(window[2 * (16 * n1 + q)], window[2 * (16 * n1 + q) + 1]);
+#pragma unroll
+        for (int n1 = 0; n1 < (kFrameSize + 31) / 32; ++n1) x[n1] = x[n1] * wv[n1];
       }
 #ifndef MFCC_ABL_FFT
       fft16(x);
@@ -470,6 +474,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     // ---- mel filterbank on the matrix cores: D[frame][col] = sum_bin P[frame][bin] W[bin][col]
 #ifndef MFCC_ABL_STAGE
     stage_ld(tb + kBatch);  // unconditional and branch-free; HBM latency runs under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the matrix-core chain
 #endif
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -536,7 +541,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     // wave waits for another.  lbuf/epbuf are rewritten only after the next spectrum barrier.
 #ifndef MFCC_ABL_DCT
     {
-      const int nd = pc->map.ndct;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const float* Lr = lbuf + q * kLogPitch + g4;
 #pragma unroll
