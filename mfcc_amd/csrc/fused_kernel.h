@@ -320,7 +320,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     stage_store<T>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
     return sr.delta;
   };
-  const int nd = pc->map.ndct;
   // floor of the mel energies: 0 = none (ln 0 = -inf as the reference, mfcc-self5.py:125-127)
   const float mel_floor = pc->floor_mel != 0 ? kEps64 : 0.f;
 
@@ -380,6 +379,11 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
         for (int n1 = 0; n1 < (kFrameSize + 31) / 32; ++n1) x[n1] = x[n1] * wv[n1];
       }
+      // stage-1 twiddles of this lane: read now (their latency hides under the first 16-point
+      // transform); reading them between the exchange writes would serialise on LDS round trips
+      cf tw1[15];
+#pragma unroll
+      for (int k1 = 1; k1 < 16; ++k1) tw1[k1 - 1] = twq[k1 - 1];
 #ifndef MFCC_ABL_FFT
       fft16(x);
 #endif
@@ -394,7 +398,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) {
 #ifndef MFCC_ABL_FFT
-        if (k1) x[k1] = cmul(x[k1], twq[k1 - 1]);
+        if (k1) x[k1] = cmul(x[k1], tw1[k1 - 1]);
 #endif
         *(cf*)(lds0 + (wbase ^ ((k1 & 14) << 3)) + k1 * 128) = x[k1];
       }
@@ -451,6 +455,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         if (q == 0) P[256] = __builtin_amdgcn_sqrtf(P[256]);
       }
     }
+#if !defined(MFCC_ABL_STAGE) && defined(MFCC_EARLY_STAGE)
+    stage_ld(tb + kBatch);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     MFCC_STAMP(tb1);
     __syncthreads();  // spectrum rows complete; staged audio no longer needed
     MFCC_STAMP(tb2);
@@ -472,7 +480,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     }
 
     // ---- mel filterbank on the matrix cores: D[frame][col] = sum_bin P[frame][bin] W[bin][col]
-#ifndef MFCC_ABL_STAGE
+#if !defined(MFCC_ABL_STAGE) && !defined(MFCC_EARLY_STAGE)
     stage_ld(tb + kBatch);  // unconditional and branch-free; HBM latency runs under the MFMAs below
     __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the matrix-core chain
 #endif
@@ -484,10 +492,13 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // are issued ahead of the chain); steps a wave does not need carry zero weights, and the
       // plan keeps kstart + 4*kMelSteps inside the zero-padded row.  Two accumulators: the MFMA
       // dependency chain is half as long.
+      float pa[kMelSteps];
+#pragma unroll
+      for (int s = 0; s < kMelSteps; ++s) pa[s] = Prow[4 * s];
 #pragma unroll
       for (int s = 0; s < kMelSteps; s += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s], bv[s], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Prow[4 * s + 4], bv[s + 1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], bv[s], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s + 1], bv[s + 1], acc2, 0, 0, 0);
       }
       acc += acc2;
 #else
@@ -541,11 +552,24 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     // wave waits for another.  lbuf/epbuf are rewritten only after the next spectrum barrier.
 #ifndef MFCC_ABL_DCT
     {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // All kDctSteps k-steps run (no branch between them, operands are read ahead of the
+      // chain): rows of dctb past the plan's nmel are zero and the ln-mel columns they meet are
+      // never written (zero).  Two accumulators halve the dependency chain.
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
       const float* Lr = lbuf + q * kLogPitch + g4;
+      float la[kDctSteps], lb[kDctSteps];
 #pragma unroll
-      for (int s = 0; s < kDctSteps; ++s)
-        if (s < nd) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Lr[4 * s], dctb[s * 64 + lane], acc, 0, 0, 0);
+      for (int s = 0; s < kDctSteps; ++s) {
+        la[s] = Lr[4 * s];
+        lb[s] = dctb[s * 64 + lane];
+      }
+#pragma unroll
+      for (int s = 0; s < kDctSteps; s += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[s], lb[s], acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(la[s + 1], lb[s + 1], accb, 0, 0, 0);
+      }
+      acc += accb;
+      static_assert(kDctSteps % 2 == 0, "DCT k-steps are issued in pairs");
       // The four waves hold the same product: wave w stores row 4*g4 + w of every lane group
       // (one store instruction with all four groups active).  c0 := ln E, floored at the
       // float64 epsilon (mfcc-self5.py:130-132 and :164).
