@@ -49,14 +49,14 @@ def _oracle_job(seed_and_count):
 
 
 def cpu_baseline():
-    """~15-25 s of CPU work: 1 core first, then a process pool on the box's CPU share."""
+    """~20 s of CPU work: ~6 s on 1 core first, then ~10 s per worker of a process pool on the box's CPU share."""
     import multiprocessing as mp
     f1, t1 = _oracle_job((1, 8))                      # calibrate (also warms caches)
     per_utt = t1 / 8
-    n1 = max(8, min(400, int(6.0 / per_utt)))
+    n1 = max(8, min(4000, int(6.0 / per_utt)))
     f1, t1 = _oracle_job((2, n1))
     cores = max(1, min(16, os.cpu_count() or 1))
-    per_worker = max(4, min(400, int(8.0 / per_utt)))
+    per_worker = max(4, min(4000, int(10.0 / per_utt)))
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
         pool.map(_oracle_job, [(100 + i, 1) for i in range(cores)])   # start-up outside the clock
@@ -152,6 +152,14 @@ def main():
         value = total_frames * args.steps / elapsed
         bytes_per_launch = 2 * N_UTT * UTT_LEN + 4 * 39 * frames          # int16 in + fp32 out
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = traffic_bytes = None
+        tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+        if os.path.exists(tpath) and args.variant == "self5":
+            # HBM bytes per launch of this very workload, from separate rocprofv3 --pmc passes
+            # (FETCH_SIZE doubled as gfx950 requires, + WRITE_SIZE); counters cannot run inside this process
+            with open(tpath) as fh:
+                traffic_bytes = json.load(fh)["hbm_bytes_per_launch"]
+            traffic = round(traffic_bytes / (kernel_ms * 1e-3) / 1e9, 1)
         rec = {
             "metric": "MFCC-39 frames/sec (whole node)",
             "value": round(value, 1),
@@ -176,9 +184,11 @@ def main():
             "x_realtime": round(value / 100.0, 1),
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "mfcc::fused_kernel<0>", "kernel_ms": round(kernel_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "mfcc::fused_kernel<0, 13, short>", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                "traffic_bytes_per_launch": traffic_bytes,
+                "traffic_source": "profiles/r1_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
             },
         }
         if cpu is not None:

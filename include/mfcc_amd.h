@@ -4,8 +4,8 @@
  * The reference (Robomate/mfcc) has no FFI layer: its hot path is thirteen
  * module-level numpy functions in mfcc-self5.py / mfcc-self15.py called only by
  * their own main().  Each entry point below therefore cites the reference
- * FUNCTION it replaces (file:line into /root/reference); the ctypes binding a
- * maintainer adds is shown in INTEGRATION.md and shipped as mfcc_amd/_capi.py.
+ * FUNCTION it replaces (file:line of the reference repository); the ctypes
+ * binding a maintainer adds is shipped as mfcc_amd/_capi.py.
  *
  * Conventions
  *   - every function returns MFCC_OK (0) or a negative MFCC_ERR_* code; the
