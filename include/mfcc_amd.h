@@ -151,6 +151,31 @@ int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, i
 int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, const float* mm, const float* vv,
                     void* stream);
 
+/* ---- streaming ------------------------------------------------------------------------
+ * n_streams live streams that advance in lock step (every push brings the same number of
+ * samples for each).  The reference has no incremental routine -- its live script queues
+ * microphone blocks (get_mic_input_13.py:28-65) and featurises a whole recording
+ * (inference_ctc_eri_05.py:464-487) -- so the contract is: the rows returned by all pushes and
+ * the final flush, concatenated, equal mfcc_forward(MFCC_OUT_MFCC39) of the concatenated audio
+ * (main(), mfcc-self5.py:211-229), including y[0]=x[0], the zero-padded last frame and the
+ * delta edge replication.  A row is returned once the 4 frames after it are complete (delta of
+ * delta reaches 4 frames ahead); flush returns the rest and starts a new utterance.
+ *
+ * chunk: [n_streams, n] samples of the dtype given at creation, row stride chunk_ld;
+ * out:   stream b's rows at out + b*out_stream_stride + i*out_ld, i < *n_rows_host, which is
+ *        known on return (host bookkeeping only; the device work is enqueued on `stream`).
+ * All calls on one mfcc_stream must use the same HIP stream (or be ordered by the caller).
+ * Nothing is allocated after create. */
+int mfcc_stream_create(const mfcc_plan* plan, int32_t n_streams, int32_t max_chunk, int32_t audio_dtype,
+                       mfcc_stream** out);
+int mfcc_stream_destroy(mfcc_stream* s);
+int mfcc_stream_reset(mfcc_stream* s); /* drop pending state; the next push starts new utterances */
+int32_t mfcc_stream_max_rows(const mfcc_stream* s); /* upper bound of rows per stream of one push / flush */
+int mfcc_stream_push(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int32_t n, float* out,
+                     int64_t out_stream_stride, int64_t out_ld, int32_t* n_rows_host, void* stream);
+int mfcc_stream_flush(mfcc_stream* s, float* out, int64_t out_stream_stride, int64_t out_ld, int32_t* n_rows_host,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,12 @@ SIGNATURES = {
     "mfcc_stack_context": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "mfcc_cmvn_accumulate": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "mfcc_cmvn_apply": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "mfcc_stream_create": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "mfcc_stream_destroy": (C.c_int, [_vp]),
+    "mfcc_stream_reset": (C.c_int, [_vp]),
+    "mfcc_stream_max_rows": (_i32, [_vp]),
+    "mfcc_stream_push": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i64, _i32p, _vp]),
+    "mfcc_stream_flush": (C.c_int, [_vp, _vp, _i64, _i64, _i32p, _vp]),
 }
 
 _lib = None

@@ -111,6 +111,7 @@ struct FusedParams {
   const void* audio;
   int64_t total_elems;        // elements in `audio`, >= 1 (bounds the 16-byte staging loads)
   const int64_t* sample_off;  // [n_utts + 1]
+  const int64_t* sample_len;  // [n_utts] or nullptr = sample_off[u+1] - sample_off[u]
   const int64_t* frame_off;   // [n_utts + 1]
   const Tile* tiles;
   float* out;
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const PlanConst* const pc = p.pc;
   const Tile tile = p.tiles[blockIdx.x];
   const int64_t s_off = p.sample_off[tile.utt];
-  const int64_t len = p.sample_off[tile.utt + 1] - s_off;
+  const int64_t len = p.sample_len ? p.sample_len[tile.utt] : p.sample_off[tile.utt + 1] - s_off;
   const int64_t f_off = p.frame_off[tile.utt];
   const int nframes = (int)(p.frame_off[tile.utt + 1] - f_off);
   const int t0 = tile.t0, nt = tile.nt;

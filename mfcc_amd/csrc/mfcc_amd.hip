@@ -13,6 +13,7 @@
 
 #include "fused_kernel.h"
 #include "stage_kernels.h"
+#include "stream_kernels.h"
 #include "tables.h"
 
 namespace {
@@ -70,10 +71,60 @@ struct mfcc_layout {
   int64_t n_tiles;
 };
 
+struct mfcc_stream {
+  const mfcc_plan* plan = nullptr;
+  int device = 0;
+  int32_t n_streams = 0, max_chunk = 0, dtype = 0, cap = 0, rows = 0, tile_max = 0, max_tiles = 0;
+  void* seg = nullptr;             // [2][n_streams][cap] samples
+  float* stat = nullptr;           // [2][n_streams][rows][kMaxCep]
+  int64_t* d_sample_off = nullptr; // per-step layout of the fused kernel, written on the device
+  int64_t* d_sample_len = nullptr;
+  int64_t* d_frame_off = nullptr;
+  mfcc::Tile* d_tiles = nullptr;
+  // host-side state, identical for all streams (they advance in lock step)
+  int64_t total = 0;      // samples pushed since the utterance began
+  int64_t seg_start = 0;  // utterance sample held at element 0 of the current segment
+  int64_t f_done = 0;     // static rows computed
+  int64_t e_done = 0;     // output rows emitted
+  int32_t half = 0, prev_new_rows = 0;
+};
+
 #ifdef MFCC_DIAG
 static unsigned long long* g_dbg = nullptr;
 extern "C" void mfcc_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 #endif
+
+#ifndef MFCC_EXTRA_SMEM
+#define MFCC_EXTRA_SMEM 0  // occupancy experiments only
+#endif
+
+// One workgroup per tile; template arguments select the output kind, a compile-time numcep of 13
+// where it pays, and the sample type.
+static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int64_t n_tiles, int32_t out_kind, bool i16,
+                         hipStream_t st) {
+  const dim3 grid((unsigned)n_tiles), block(256);
+  const size_t smem = mfcc::kSmemFloats * sizeof(float) + MFCC_EXTRA_SMEM;
+  const bool c13 = plan->cfg.numcep == 13;
+#define MFCC_LAUNCH(OUT, NCEP)                                                                               \
+  do {                                                                                                       \
+    if (i16) hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, int16_t>), grid, block, smem, st, fp);        \
+    else hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, float>), grid, block, smem, st, fp);              \
+  } while (0)
+  switch (out_kind) {
+    case MFCC_OUT_MFCC39:
+      if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39, 13);
+      else MFCC_LAUNCH(mfcc::kOutMfcc39, 0);
+      break;
+    case MFCC_OUT_STATIC:
+      if (c13) MFCC_LAUNCH(mfcc::kOutStatic, 13);
+      else MFCC_LAUNCH(mfcc::kOutStatic, 0);
+      break;
+    case MFCC_OUT_LOGMEL: MFCC_LAUNCH(mfcc::kOutLogmel, 0); break;
+    case MFCC_OUT_SPEC: MFCC_LAUNCH(mfcc::kOutSpec, 0); break;
+    case MFCC_OUT_LOGSPEC: MFCC_LAUNCH(mfcc::kOutLogspec, 0); break;
+  }
+#undef MFCC_LAUNCH
+}
 
 extern "C" {
 
@@ -393,6 +444,7 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   mfcc::FusedParams fp;
   fp.audio = audio;
   fp.sample_off = layout->d_sample_off;
+  fp.sample_len = nullptr;
   fp.frame_off = layout->d_frame_off;
   fp.tiles = layout->d_tiles;
   fp.out = out;
@@ -409,33 +461,7 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   fp.dbg = g_dbg;
 #endif
 
-  const dim3 grid((unsigned)layout->n_tiles), block(256);
-#ifndef MFCC_EXTRA_SMEM
-#define MFCC_EXTRA_SMEM 0  // occupancy experiments only
-#endif
-  const size_t smem = mfcc::kSmemFloats * sizeof(float) + MFCC_EXTRA_SMEM;
-  hipStream_t st = (hipStream_t)stream;
-  const bool c13 = plan->cfg.numcep == 13;
-  const bool i16 = audio_dtype == MFCC_AUDIO_I16;
-#define MFCC_LAUNCH(OUT, NCEP)                                                                               \
-  do {                                                                                                       \
-    if (i16) hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, int16_t>), grid, block, smem, st, fp);        \
-    else hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, float>), grid, block, smem, st, fp);              \
-  } while (0)
-  switch (out_kind) {
-    case MFCC_OUT_MFCC39:
-      if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39, 13);
-      else MFCC_LAUNCH(mfcc::kOutMfcc39, 0);
-      break;
-    case MFCC_OUT_STATIC:
-      if (c13) MFCC_LAUNCH(mfcc::kOutStatic, 13);
-      else MFCC_LAUNCH(mfcc::kOutStatic, 0);
-      break;
-    case MFCC_OUT_LOGMEL: MFCC_LAUNCH(mfcc::kOutLogmel, 0); break;
-    case MFCC_OUT_SPEC: MFCC_LAUNCH(mfcc::kOutSpec, 0); break;
-    case MFCC_OUT_LOGSPEC: MFCC_LAUNCH(mfcc::kOutLogspec, 0); break;
-  }
-#undef MFCC_LAUNCH
+  launch_fused(plan, fp, layout->n_tiles, out_kind, audio_dtype == MFCC_AUDIO_I16, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
 }
@@ -546,11 +572,183 @@ int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol
   if (n_rows < 0 || ncol < 1 || feats_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_apply: bad shape");
   if (n_rows == 0) return MFCC_OK;
   if (!feats || !mm || !vv) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_apply: null pointer");
-  const int64_t total = n_rows * ncol;
-  hipLaunchKernelGGL(mfcc::cmvn_apply_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, feats, feats_ld, n_rows, ncol,
-                     mm, vv);
+  if (ncol > 4096) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_cmvn_apply: more than 4096 columns");
+  const int rows_per_block = std::max(1, 16384 / ncol);
+  const int64_t nblk = (n_rows + rows_per_block - 1) / rows_per_block;
+  if (nblk > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_cmvn_apply: too many rows per call");
+  hipLaunchKernelGGL(mfcc::cmvn_apply_kernel, dim3((unsigned)nblk), dim3(256), 2 * ncol * sizeof(float), (hipStream_t)stream, feats,
+                     feats_ld, n_rows, ncol, mm, vv, rows_per_block);
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
+}
+
+/* ---- streaming ------------------------------------------------------------------------- */
+
+int mfcc_stream_create(const mfcc_plan* plan, int32_t n_streams, int32_t max_chunk, int32_t audio_dtype, mfcc_stream** out) {
+  if (!plan || !out) return fail(MFCC_ERR_INVALID, "mfcc_stream_create: null argument");
+  *out = nullptr;
+  if (n_streams < 1 || n_streams > 65535) return fail(MFCC_ERR_INVALID, "n_streams=%d outside 1..65535", n_streams);
+  if (max_chunk < 1 || max_chunk > (1 << 24)) return fail(MFCC_ERR_INVALID, "max_chunk=%d outside 1..2^24", max_chunk);
+  if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
+  if (plan->cfg.pad_fac != 2) return fail(MFCC_ERR_UNSUPPORTED, "streaming implements pad_fac=2");
+  HIP_TRY(hipSetDevice(plan->device));
+  mfcc_stream* s = new (std::nothrow) mfcc_stream();
+  if (!s) return fail(MFCC_ERR_NOMEM, "mfcc_stream_create: out of host memory");
+  s->plan = plan;
+  s->device = plan->device;
+  s->n_streams = n_streams;
+  s->max_chunk = max_chunk;
+  s->dtype = audio_dtype;
+  // a segment holds the carried tail (< frame_size + frame_step samples) and one chunk
+  s->cap = (plan->frame_size + plan->frame_step + max_chunk + 15) / 8 * 8;
+  const int32_t max_new = max_chunk / plan->frame_step + 2;
+  s->rows = mfcc::kStreamHalo + max_new;
+  s->tile_max = mfcc::tile_frames_for(plan->cfg.numcep);
+  s->max_tiles = (max_new + s->tile_max - 1) / s->tile_max;
+  const size_t esz = audio_dtype == MFCC_AUDIO_I16 ? 2 : 4;
+  const size_t seg_bytes = (size_t)2 * n_streams * s->cap * esz;
+  const size_t stat_bytes = (size_t)2 * n_streams * s->rows * mfcc::kMaxCep * sizeof(float);
+  hipError_t e = hipMalloc(&s->seg, seg_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->stat, stat_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_sample_off, (n_streams + 1) * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_sample_len, (n_streams + 1) * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_frame_off, (n_streams + 1) * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_tiles, (size_t)n_streams * s->max_tiles * sizeof(mfcc::Tile));
+  if (e == hipSuccess) e = hipMemset(s->seg, 0, seg_bytes);
+  if (e == hipSuccess) e = hipMemset(s->stat, 0, stat_bytes);
+  if (e != hipSuccess) {
+    mfcc_stream_destroy(s);
+    return fail(MFCC_ERR_NOMEM, "mfcc_stream_create: %s", hipGetErrorString(e));
+  }
+  *out = s;
+  return MFCC_OK;
+}
+
+int mfcc_stream_destroy(mfcc_stream* s) {
+  if (!s) return MFCC_OK;
+  (void)hipFree(s->seg);
+  (void)hipFree(s->stat);
+  (void)hipFree(s->d_sample_off);
+  (void)hipFree(s->d_sample_len);
+  (void)hipFree(s->d_frame_off);
+  (void)hipFree(s->d_tiles);
+  delete s;
+  return MFCC_OK;
+}
+
+int mfcc_stream_reset(mfcc_stream* s) {
+  if (!s) return fail(MFCC_ERR_INVALID, "mfcc_stream_reset: null stream");
+  s->total = s->seg_start = s->f_done = s->e_done = 0;
+  s->prev_new_rows = 0;
+  return MFCC_OK;
+}
+
+int32_t mfcc_stream_max_rows(const mfcc_stream* s) {
+  if (!s) return fail(MFCC_ERR_INVALID, "mfcc_stream_max_rows: null stream");
+  return s->max_chunk / s->plan->frame_step + 2 + 2 * mfcc::kHalo;
+}
+
+// One step: append n samples per stream (n may be 0), compute the static rows of the frames
+// f_done .. f_target-1, emit output rows e_done .. e_target-1.
+static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int32_t n, int64_t f_target, int64_t e_target,
+                       bool last, float* out, int64_t out_stream_stride, int64_t out_ld, hipStream_t st) {
+  const mfcc_plan* plan = s->plan;
+  const int32_t step = plan->frame_step;
+  const int64_t start = s->f_done > 0 ? (s->f_done - 1) * step : 0;  // one frame of history: the pre-emphasis predecessor
+  mfcc::StreamStep ss;
+  ss.n_streams = s->n_streams;
+  ss.cap = s->cap;
+  ss.rows = s->rows;
+  ss.src_half = s->half;
+  ss.src_skip = (int32_t)(start - s->seg_start);
+  ss.keep = (int32_t)(s->total - start);
+  ss.n_new = n;
+  ss.prev_new_rows = s->prev_new_rows;
+  ss.t0 = s->f_done > 0 ? 1 : 0;
+  ss.nt = (int32_t)(f_target - s->f_done);
+  ss.tile_max = s->tile_max;
+  ss.tiles_per_stream = (ss.nt + s->tile_max - 1) / s->tile_max;
+  if (ss.keep + n > s->cap || ss.nt > s->rows - mfcc::kStreamHalo || ss.tiles_per_stream > s->max_tiles)
+    return fail(MFCC_ERR_INVALID, "mfcc_stream: internal capacity exceeded (keep %d, n %d, new frames %d)", ss.keep, n, ss.nt);
+  const int total = ss.keep + n;
+  const dim3 agrid((unsigned)std::max(1, std::min(64, (total + 255) / 256)), (unsigned)s->n_streams);
+  if (s->dtype == MFCC_AUDIO_I16)
+    hipLaunchKernelGGL(mfcc::stream_append_kernel<int16_t>, agrid, dim3(256), 0, st, ss, (int16_t*)s->seg, s->stat,
+                       (const int16_t*)chunk, chunk_ld, s->d_sample_off, s->d_sample_len, s->d_frame_off, s->d_tiles);
+  else
+    hipLaunchKernelGGL(mfcc::stream_append_kernel<float>, agrid, dim3(256), 0, st, ss, (float*)s->seg, s->stat,
+                       (const float*)chunk, chunk_ld, s->d_sample_off, s->d_sample_len, s->d_frame_off, s->d_tiles);
+  const int32_t new_half = s->half ^ 1;
+  if (ss.nt > 0) {
+    mfcc::FusedParams fp;
+    fp.audio = s->seg;
+    fp.total_elems = (int64_t)2 * s->n_streams * s->cap;
+    fp.sample_off = s->d_sample_off;
+    fp.sample_len = s->d_sample_len;
+    fp.frame_off = s->d_frame_off;
+    fp.tiles = s->d_tiles;
+    fp.out = s->stat;
+    fp.out_ld = mfcc::kMaxCep;
+    fp.pc = plan->pc;
+#ifdef MFCC_DIAG
+    fp.dbg = nullptr;
+#endif
+    launch_fused(plan, fp, (int64_t)s->n_streams * ss.tiles_per_stream, MFCC_OUT_STATIC, s->dtype == MFCC_AUDIO_I16, st);
+  }
+  const int64_t k = e_target - s->e_done;
+  if (k > 0) {
+    // frame numbers relative to the first new static row (utterance frame f_done)
+    const int64_t big = 1 << 28;
+    const int32_t e0 = (int32_t)(s->e_done - s->f_done);
+    const int32_t lo = (int32_t)std::max(-s->f_done, -big);
+    const int32_t hi = last ? (int32_t)(f_target - 1 - s->f_done) : (int32_t)big;
+    const int64_t work = (int64_t)s->n_streams * k * mfcc::kMaxCep;
+    hipLaunchKernelGGL(mfcc::stream_emit_kernel, dim3(blocks_for(work, 256)), dim3(256), 0, st, s->stat, new_half, s->n_streams,
+                       s->rows, e0, (int32_t)k, lo, hi, plan->cfg.numcep, out, out_stream_stride, out_ld);
+  }
+  HIP_TRY(hipGetLastError());
+  s->half = new_half;
+  s->seg_start = start;
+  s->total += n;
+  s->prev_new_rows = ss.nt;
+  s->f_done = f_target;
+  s->e_done = e_target;
+  return MFCC_OK;
+}
+
+int mfcc_stream_push(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int32_t n, float* out, int64_t out_stream_stride,
+                     int64_t out_ld, int32_t* n_rows_host, void* stream) {
+  if (!s) return fail(MFCC_ERR_INVALID, "mfcc_stream_push: null stream");
+  if (n_rows_host) *n_rows_host = 0;
+  if (n < 0 || n > s->max_chunk) return fail(MFCC_ERR_INVALID, "chunk of %d samples, the stream was created for at most %d", n, s->max_chunk);
+  if (n == 0) return MFCC_OK;
+  if (!chunk || chunk_ld < n) return fail(MFCC_ERR_INVALID, "mfcc_stream_push: bad chunk pointer or stride");
+  const int32_t width = 3 * s->plan->cfg.numcep;
+  const int64_t total = s->total + n;
+  const int64_t complete = total >= s->plan->frame_size ? (total - s->plan->frame_size) / s->plan->frame_step + 1 : 0;
+  const int64_t emit = std::max<int64_t>(complete - mfcc::kHalo, s->e_done);  // rows whose +4-frame context exists
+  const int64_t k = emit - s->e_done;
+  if (k > 0 && (!out || out_ld < width || out_stream_stride < k * out_ld))
+    return fail(MFCC_ERR_INVALID, "mfcc_stream_push: out must hold %lld rows of %d floats per stream", (long long)k, width);
+  const int rc = stream_step(s, chunk, chunk_ld, n, complete, emit, false, out, out_stream_stride, out_ld, (hipStream_t)stream);
+  if (rc) return rc;
+  if (n_rows_host) *n_rows_host = (int32_t)k;
+  return MFCC_OK;
+}
+
+int mfcc_stream_flush(mfcc_stream* s, float* out, int64_t out_stream_stride, int64_t out_ld, int32_t* n_rows_host, void* stream) {
+  if (!s) return fail(MFCC_ERR_INVALID, "mfcc_stream_flush: null stream");
+  if (n_rows_host) *n_rows_host = 0;
+  if (s->total == 0) return MFCC_OK;  // nothing was pushed: no utterance, no rows
+  const int32_t width = 3 * s->plan->cfg.numcep;
+  const int64_t frames = mfcc::frames_for_length(s->total, s->plan->frame_size, s->plan->frame_step);
+  const int64_t k = frames - s->e_done;
+  if (!out || out_ld < width || out_stream_stride < k * out_ld)
+    return fail(MFCC_ERR_INVALID, "mfcc_stream_flush: out must hold %lld rows of %d floats per stream", (long long)k, width);
+  const int rc = stream_step(s, nullptr, 0, 0, frames, frames, true, out, out_stream_stride, out_ld, (hipStream_t)stream);
+  if (rc) return rc;
+  if (n_rows_host) *n_rows_host = (int32_t)k;
+  return mfcc_stream_reset(s);
 }
 
 }  // extern "C"

@@ -106,21 +106,59 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int64_t src_ld, 
 
 // Context stacking, MLP_5hidlayer_40.py:70-105: one workgroup per output row t of
 // utterance u; out[t, f*C + c] = feats[clamp(t + f - h), c].  The write of N*C contiguous
-// floats per row is the traffic that matters (17 x the read).
-__global__ void stack_context_kernel(const float* __restrict__ feats, int64_t feats_ld, int ncol, int framenum,
-                                     const int64_t* __restrict__ frame_off, const int32_t* __restrict__ row_utt,
-                                     float* __restrict__ out) {
+// floats per row is the traffic that matters (N x the read, which stays in L2): the row is
+// written with 16-byte non-temporal stores (a few scalar stores bring an odd row width to
+// 16-byte alignment first), the source values are gathered with 4-byte loads.
+__global__ void __launch_bounds__(256) stack_context_kernel(const float* __restrict__ feats, int64_t feats_ld, int ncol,
+                                                            int framenum, const int64_t* __restrict__ frame_off,
+                                                            const int32_t* __restrict__ row_utt, float* __restrict__ out) {
   const int64_t row = blockIdx.x;
   const int u = row_utt[row];
   const int64_t f0 = frame_off[u], f1 = frame_off[u + 1];
   const int half = (framenum - 1) / 2;
   const int width = framenum * ncol;
-  float* o = out + row * (int64_t)width;
-  for (int i = threadIdx.x; i < width; i += blockDim.x) {
-    const int f = i / ncol, c = i - f * ncol;
+  float* const o = out + row * (int64_t)width;
+  auto src_row = [&](int f) {
     int64_t t = row + f - half;
     t = t < f0 ? f0 : (t > f1 - 1 ? f1 - 1 : t);
-    o[i] = feats[t * feats_ld + c];
+    return feats + t * feats_ld;
+  };
+  const int lead = min(width, (int)((4 - (((uintptr_t)o >> 2) & 3)) & 3));  // floats up to the next 16-byte boundary
+  if ((int)threadIdx.x < lead) {
+    const int e = threadIdx.x, ff = e / ncol;
+    o[e] = src_row(ff)[e - ff * ncol];
+  }
+  const int nvec = (width - lead) >> 2;
+  // element index of this thread's chunk and its (frame, column) split, advanced incrementally
+  int i = lead + 4 * (int)threadIdx.x;
+  int f = i / ncol, c = i - f * ncol;
+  const int di = 4 * (int)blockDim.x, df = di / ncol, dc = di - df * ncol;
+  for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
+    float val[4];
+    if (c + 3 < ncol) {
+      const float* sp = src_row(f) + c;
+      val[0] = sp[0]; val[1] = sp[1]; val[2] = sp[2]; val[3] = sp[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int cc = c + j, ff = f;
+        while (cc >= ncol) { cc -= ncol; ++ff; }
+        val[j] = src_row(ff)[cc];
+      }
+    }
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    f32x4_t pk = {val[0], val[1], val[2], val[3]};
+    __builtin_nontemporal_store(pk, (f32x4_t*)(o + i));
+    i += di;
+    f += df;
+    c += dc;
+    if (c >= ncol) { c -= ncol; ++f; }
+  }
+  const int done = lead + 4 * nvec;
+  if ((int)threadIdx.x < width - done) {
+    const int e = done + threadIdx.x;
+    const int ff = e / ncol;
+    o[e] = src_row(ff)[e - ff * ncol];
   }
 }
 
@@ -158,14 +196,31 @@ __global__ void cmvn_accumulate_kernel(const float* __restrict__ x, int64_t ld, 
   if (threadIdx.x == 0) atomicAdd(&sums[0], (double)(r1 - r0));
 }
 
-__global__ void cmvn_apply_kernel(float* __restrict__ x, int64_t ld, int64_t n_rows, int ncol,
-                                  const float* __restrict__ mm, const float* __restrict__ vv) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_rows * ncol) return;
-  const int64_t r = idx / ncol;
-  const int c = (int)(idx - r * ncol);
-  float* p = x + r * ld + c;
-  *p = (*p + mm[c]) * vv[c];  // (x + mm) .* vv, anal_recog_nn_liste.m:180
+// (x + mm) .* vv in place (the form of anal_recog_nn_liste.m:180).  A workgroup owns a slab of
+// rows; consecutive threads touch consecutive elements and track (row, column) incrementally,
+// so there is no division per element.  mm / vv sit in LDS.
+__global__ void __launch_bounds__(256) cmvn_apply_kernel(float* __restrict__ x, int64_t ld, int64_t n_rows, int ncol,
+                                                         const float* __restrict__ mm, const float* __restrict__ vv,
+                                                         int rows_per_block) {
+  extern __shared__ float cm[];  // [2][ncol]
+  for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
+    cm[i] = mm[i];
+    cm[ncol + i] = vv[i];
+  }
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int nr = (int)(n_rows - r0 < rows_per_block ? n_rows - r0 : rows_per_block);
+  const int total = nr * ncol;
+  int r = threadIdx.x / ncol, c = threadIdx.x - r * ncol;
+  const int dr = blockDim.x / ncol, dc = blockDim.x - dr * ncol;
+  float* const base = x + r0 * ld;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    float* p = base + (int64_t)r * ld + c;
+    *p = (*p + cm[c]) * cm[ncol + c];
+    r += dr;
+    c += dc;
+    if (c >= ncol) { c -= ncol; ++r; }
+  }
 }
 
 }  // namespace mfcc

@@ -1,0 +1,96 @@
+// Kernels of the streaming path: B live streams advance in lock step; each push appends a
+// chunk per stream, the fused kernel (static-feature mode) turns the new complete frames into
+// static rows, and stream_emit_kernel forms delta / delta-delta for the rows whose +-4-frame
+// context is complete.  The reference has no incremental path (its live script queues
+// microphone blocks, get_mic_input_13.py:28-65, and featurises whole utterances,
+// inference_ctc_eri_05.py:464-487); results are defined by equality with the whole-utterance
+// path (mfcc-self5.py:211-229) on the concatenated audio.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fused_kernel.h"
+
+namespace mfcc {
+
+constexpr int kStreamHalo = 2 * kHalo;  // static rows kept from earlier pushes (delta-delta reaches 4 back)
+
+struct StreamStep {
+  // audio segments: [2][B][cap] samples, statics: [2][B][rows][kMaxCep] floats (ping-pong halves)
+  int32_t n_streams, cap, rows;
+  int32_t src_half;      // half holding the previous segment / statics
+  int32_t src_skip;      // samples of the previous segment to drop from its front
+  int32_t keep;          // samples of the previous segment carried over
+  int32_t n_new;         // samples appended per stream
+  int32_t prev_new_rows; // static rows the previous step computed (its rows kStreamHalo .. +prev_new_rows)
+  int32_t t0, nt;        // first new frame (segment-relative) and number of new frames
+  int32_t tile_max;      // frames per tile of the fused kernel
+  int32_t tiles_per_stream;
+};
+
+// One launch per push: (1) new segment = [carried tail | chunk], (2) the last kStreamHalo static
+// rows move to the front of the other half, (3) the per-step layout of the fused kernel
+// (offsets, lengths, tiles) is written from the scalars above -- no host-to-device copy.
+template <typename T>
+__global__ void __launch_bounds__(256) stream_append_kernel(const StreamStep s, T* seg, float* stat, const T* chunk,
+                                                            int64_t chunk_ld, int64_t* sample_off, int64_t* sample_len,
+                                                            int64_t* frame_off, Tile* tiles) {
+  const int b = blockIdx.y;
+  const int dst_half = s.src_half ^ 1;
+  T* const dst = seg + ((int64_t)dst_half * s.n_streams + b) * s.cap;
+  const T* const src = seg + ((int64_t)s.src_half * s.n_streams + b) * s.cap + s.src_skip;
+  const int total = s.keep + s.n_new;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256)
+    dst[i] = i < s.keep ? src[i] : chunk[(int64_t)b * chunk_ld + (i - s.keep)];
+  if (blockIdx.x == 0) {
+    float* const sd = stat + ((int64_t)dst_half * s.n_streams + b) * s.rows * kMaxCep;
+    const float* const ss = stat + ((int64_t)s.src_half * s.n_streams + b) * s.rows * kMaxCep + s.prev_new_rows * kMaxCep;
+    for (int i = threadIdx.x; i < kStreamHalo * kMaxCep; i += 256) sd[i] = ss[i];
+    if (threadIdx.x == 0) {
+      sample_off[b] = ((int64_t)dst_half * s.n_streams + b) * s.cap;
+      sample_len[b] = total;
+      // row (frame_off + t) of the statics array holds segment frame t; the first new frame t0
+      // lands on row kStreamHalo of this stream's block
+      frame_off[b] = ((int64_t)dst_half * s.n_streams + b) * s.rows + kStreamHalo - s.t0;
+      for (int j = 0; j < s.tiles_per_stream; ++j) {
+        const int first = s.t0 + j * s.tile_max;
+        const int n = min(s.tile_max, s.t0 + s.nt - first);
+        tiles[b * s.tiles_per_stream + j] = Tile{b, first, n > 0 ? n : 0, 0};
+      }
+      if (b == 0) {
+        sample_off[s.n_streams] = 0;  // never read: lengths come from sample_len
+        frame_off[s.n_streams] = 0;
+      }
+    }
+  }
+}
+
+// Rows e0 .. e0+k-1 of every stream: [c | delta | delta-delta] with the regression of
+// mfcc-self5.py:169-179 applied twice.  Frame numbers are relative to the first frame of this
+// step's new statics (which sits at row kStreamHalo of the stream's block) and are clamped to
+// [lo, hi]: lo = the utterance's frame 0, hi = its last frame at flush (edge replication,
+// mfcc-self5.py:174) or out of reach before.
+__global__ void __launch_bounds__(256) stream_emit_kernel(const float* stat, int32_t half, int32_t n_streams, int32_t rows,
+                                                          int32_t e0, int32_t k, int32_t lo, int32_t hi, int32_t ncep,
+                                                          float* out, int64_t out_stream_stride, int64_t out_ld) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int c = idx % kMaxCep;
+  const int i = (idx / kMaxCep) % k;
+  const int b = idx / (kMaxCep * k);
+  if (b >= n_streams || c >= ncep) return;
+  const float* const S = stat + (((int64_t)half * n_streams + b) * rows + kStreamHalo) * kMaxCep + c;
+  auto st = [&](int u) { return S[min(max(u, lo), hi) * kMaxCep]; };
+  auto reg = [](float a, float bb, float m, float d, float e) { return (2.f * (e - a) + (d - bb) + 0.f * m) * 0.1f; };
+  auto dl = [&](int v) {
+    v = min(max(v, lo), hi);
+    return reg(st(v - 2), st(v - 1), st(v), st(v + 1), st(v + 2));
+  };
+  const int e = e0 + i;
+  float* const o = out + b * out_stream_stride + i * out_ld;
+  o[c] = st(e);
+  o[ncep + c] = dl(e);
+  o[2 * ncep + c] = reg(dl(e - 2), dl(e - 1), dl(e), dl(e + 1), dl(e + 2));
+}
+
+}  // namespace mfcc

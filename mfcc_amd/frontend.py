@@ -307,6 +307,78 @@ def stack_context(feats, framenum, frame_counts=None, out=None):
 
 
 # --------------------------------------------------------------------------
+# streaming
+# --------------------------------------------------------------------------
+class StreamingMFCC:
+    """MFCC-39 for ``n_streams`` live streams that advance in lock step.
+
+    ``push(chunk)`` takes [n_streams, n] samples (n <= max_chunk, any n, e.g. the 10 ms hops of
+    a microphone queue as in get_mic_input_13.py:28-65) and returns the rows that became final,
+    [n_streams, k, 39]; a row is final once the 4 frames after it are complete.  ``flush()``
+    returns the remaining rows (zero-padded last frame, edge-replicated deltas) and starts a new
+    utterance.  All rows of one utterance, concatenated, equal the whole-utterance result
+    (main(), mfcc-self5.py:211-229) on the concatenated audio."""
+
+    def __init__(self, variant="self5", n_streams=1, max_chunk=1600, dtype=torch.int16, device=None, **overrides):
+        if dtype not in (torch.int16, torch.float32):
+            raise ValueError("dtype must be torch.int16 or torch.float32")
+        cfg = dict(VARIANTS[variant])
+        cfg.update(overrides)
+        self.plan = get_plan(device, **cfg)
+        self.n_streams, self.max_chunk, self.dtype = int(n_streams), int(max_chunk), dtype
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.plan.device):
+            capi.check(capi.load().mfcc_stream_create(self.plan._h, self.n_streams, self.max_chunk,
+                                                      capi.AUDIO_I16 if dtype == torch.int16 else capi.AUDIO_F32,
+                                                      C.byref(self._h)))
+        self.max_rows = capi.load().mfcc_stream_max_rows(self._h)
+        self.width = self.plan.out_width("mfcc39")
+
+    def _out(self):
+        return torch.empty((self.n_streams, self.max_rows, self.width), dtype=torch.float32, device=self.plan.device)
+
+    def push(self, chunk, out=None):
+        was_numpy = not isinstance(chunk, torch.Tensor)
+        t = torch.as_tensor(np.ascontiguousarray(chunk)) if was_numpy else chunk
+        if t.dim() == 1:
+            t = t.reshape(1, -1)
+        if t.dim() != 2 or t.shape[0] != self.n_streams:
+            raise ValueError(f"chunk must be [{self.n_streams}, n]")
+        if t.shape[1] > self.max_chunk:
+            raise ValueError(f"chunk of {t.shape[1]} samples, the stream was created for at most {self.max_chunk}")
+        t = t.to(self.plan.device).to(self.dtype)
+        if t.shape[1] > 0 and t.stride(1) != 1:
+            t = t.contiguous()
+        if out is None:
+            out = self._out()
+        k = C.c_int32(0)
+        with torch.cuda.device(self.plan.device):
+            capi.check(capi.load().mfcc_stream_push(self._h, _ptr(t), t.stride(0) if t.shape[1] else 0, t.shape[1],
+                                                    _ptr(out), out.stride(0), out.stride(1), C.byref(k), _stream_ptr()))
+        return _ret(out[:, :k.value], was_numpy)
+
+    def flush(self, out=None, as_numpy=False):
+        if out is None:
+            out = self._out()
+        k = C.c_int32(0)
+        with torch.cuda.device(self.plan.device):
+            capi.check(capi.load().mfcc_stream_flush(self._h, _ptr(out), out.stride(0), out.stride(1), C.byref(k),
+                                                     _stream_ptr()))
+        return _ret(out[:, :k.value], as_numpy)
+
+    def reset(self):
+        capi.check(capi.load().mfcc_stream_reset(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                capi.load().mfcc_stream_destroy(h)
+            except Exception:
+                pass
+
+
+# --------------------------------------------------------------------------
 # CMVN
 # --------------------------------------------------------------------------
 def cmvn_accumulate(feats, sums=None):

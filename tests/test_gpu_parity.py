@@ -334,3 +334,74 @@ def test_error_behaviour(M):
         M.MFCC("self5")(torch.zeros(10, dtype=torch.int16, device="cuda"), lengths=[10, 0])
     with pytest.raises(ValueError):
         M.MFCC("self5").forward(torch.zeros(10, dtype=torch.int16), None)
+
+
+# --------------------------------------------------------------------------
+# streaming: rows of all pushes + flush == whole-utterance result on the concatenated audio
+# --------------------------------------------------------------------------
+def _stream_all(s, audio, chunks):
+    """Push audio [B, L] in the given chunk sizes (cycled), then flush; returns [B, F, 39]."""
+    parts, pos, i = [], 0, 0
+    while pos < audio.shape[1]:
+        n = min(chunks[i % len(chunks)], audio.shape[1] - pos)
+        parts.append(s.push(audio[:, pos:pos + n]))
+        pos += n
+        i += 1
+    parts.append(s.flush())
+    return torch.cat(parts, dim=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["self5", "self15"])
+@pytest.mark.parametrize("chunks", [[160], [137, 1, 1000, 23], [1600], [4000, 160, 160]])
+def test_streaming_equals_offline(variant, chunks):
+    import mfcc_amd
+    from oracle import mfcc_oracle as O
+    rng = np.random.default_rng(7)
+    B, L = 3, 5000 + 37
+    audio = np.clip(rng.standard_normal((B, L)) * 3000, -32768, 32767).astype(np.int16)
+    s = mfcc_amd.StreamingMFCC(variant, n_streams=B, max_chunk=4000)
+    got = _stream_all(s, torch.from_numpy(audio).cuda(), chunks).cpu().numpy()
+    off = mfcc_amd.MFCC(variant)(torch.from_numpy(audio).cuda()).cpu().numpy().reshape(B, -1, 39)
+    assert got.shape == off.shape
+    # same kernels for the statics, same regression expression for the deltas
+    np.testing.assert_allclose(got, off, rtol=0, atol=2e-5)
+    for b in range(B):
+        assert_cep(got[b], O.mfcc39(audio[b], variant), f"stream {b}")
+    # the object is reusable: a second, shorter utterance after flush
+    got2 = _stream_all(s, torch.from_numpy(audio[:, :777]).cuda(), chunks).cpu().numpy()
+    for b in range(B):
+        assert_cep(got2[b], O.mfcc39(audio[b, :777], variant), f"stream {b} second utterance")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [1, 399, 400, 401, 560, 561, 1040, 1041])
+def test_streaming_short_utterances(L):
+    import mfcc_amd
+    from oracle import mfcc_oracle as O
+    rng = np.random.default_rng(L)
+    audio = np.clip(rng.standard_normal((2, L)) * 3000, -32768, 32767).astype(np.int16)
+    s = mfcc_amd.StreamingMFCC("self5", n_streams=2, max_chunk=320)
+    got = _stream_all(s, torch.from_numpy(audio).cuda(), [160, 77]).cpu().numpy()
+    for b in range(2):
+        ref = O.mfcc39(audio[b], "self5")
+        assert got[b].shape == ref.shape
+        assert_cep(got[b], ref, f"L={L} stream {b}")
+
+
+@pytest.mark.gpu
+def test_streaming_float_input_numpy_and_errors():
+    import mfcc_amd
+    from oracle import mfcc_oracle as O
+    rng = np.random.default_rng(3)
+    audio = (rng.standard_normal((1, 3000)) * 0.1).astype(np.float32)
+    s = mfcc_amd.StreamingMFCC("self5", n_streams=1, max_chunk=800, dtype=torch.float32)
+    parts = [s.push(audio[:, i:i + 800]) for i in range(0, 3000, 800)]
+    assert all(isinstance(p, np.ndarray) for p in parts)
+    got = np.concatenate(parts + [s.flush(as_numpy=True)], axis=1)
+    assert_cep(got[0], O.mfcc39(audio[0], "self5"), "float stream")
+    with pytest.raises(ValueError):
+        s.push(np.zeros((1, 801), np.float32))
+    with pytest.raises(ValueError):
+        s.push(np.zeros((2, 10), np.float32))
+    assert s.flush().shape[1] == 0  # nothing pushed: no rows
