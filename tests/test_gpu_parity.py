@@ -405,3 +405,25 @@ def test_streaming_float_input_numpy_and_errors():
     with pytest.raises(ValueError):
         s.push(np.zeros((2, 10), np.float32))
     assert s.flush().shape[1] == 0  # nothing pushed: no rows
+
+
+# --------------------------------------------------------------------------
+# other parameterisations of the same functions (keyword arguments of melbanks / mfcc / dctopt)
+# --------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_bins,numcep,lift,low", [(40, 13, 22, 0), (20, 13, 0, 100.0), (26, 12, 22, 0), (33, 16, 10, 0)])
+def test_other_parameterisations(num_bins, numcep, lift, low):
+    import mfcc_amd
+    rng = np.random.default_rng(11)
+    audio = np.clip(rng.standard_normal(9000) * 3000, -32768, 32767).astype(np.int16)
+    st = O.mfcc39(audio, "self5", num_bins=num_bins, low_freq=low, lift_factor=lift, return_stages=True)
+    with np.errstate(invalid="ignore"):
+        static = O.dctopt(O.dct_ortho(st["logmel"], numcep, loop=False), lift)
+        static[:, 0] = st["loge"]
+        d = O.delta(static, loop=False)
+        ref = np.concatenate([static, d, O.delta(d, loop=False)], axis=1)
+    got = mfcc_amd.mfcc39(audio, num_bins=num_bins, numcep=numcep, lift_factor=lift, low_freq=low)
+    assert got.shape == ref.shape == (st["out"].shape[0], 3 * numcep)
+    assert_cep(got, ref, f"nmel={num_bins} numcep={numcep}")
+    lm = mfcc_amd.mfcc39(audio, num_bins=num_bins, numcep=numcep, lift_factor=lift, low_freq=low, kind="logmel")
+    assert_logmel(lm[:, :num_bins], st["logmel"], "logmel")
