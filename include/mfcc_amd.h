@@ -151,6 +151,16 @@ int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, i
 int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, const float* mm, const float* vv,
                     void* stream);
 
+/* ---- sequence shaping for the recurrent / CTC consumers ------------------------------------
+ * In place per utterance of the layout: (x - mean) / std with mean and population std over ALL
+ * frames x coefficients of the utterance (inference_ctc_eri_05.py:291, CTC/ctc_test_1.py:54). */
+int mfcc_utt_scalar_norm(const mfcc_layout* layout, float* feats, int64_t feats_ld, int32_t ncol, void* stream);
+/* pad_sequences(sequences, maxlen, padding, truncating, value), CTC/utils.py:71-128 (and the
+ * zero-padded [batch, time_steps, coeffs] arrays of BiLSTM_7.py:82-124): ragged rows of the
+ * layout -> out[n_utts, time_steps, ncol]; pre_pad / pre_trunc = 1 select 'pre'. */
+int mfcc_pad_batch(const mfcc_layout* layout, const float* feats, int64_t feats_ld, int32_t ncol, int32_t time_steps,
+                   float value, int32_t pre_pad, int32_t pre_trunc, float* out, void* stream);
+
 /* ---- streaming ------------------------------------------------------------------------
  * n_streams live streams that advance in lock step (every push brings the same number of
  * samples for each).  The reference has no incremental routine -- its live script queues

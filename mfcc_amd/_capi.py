@@ -73,6 +73,8 @@ SIGNATURES = {
     "mfcc_stack_context": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "mfcc_cmvn_accumulate": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "mfcc_cmvn_apply": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "mfcc_utt_scalar_norm": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "mfcc_pad_batch": (C.c_int, [_vp, _vp, _i64, _i32, _i32, C.c_float, _i32, _i32, _vp, _vp]),
     "mfcc_stream_create": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
     "mfcc_stream_destroy": (C.c_int, [_vp]),
     "mfcc_stream_reset": (C.c_int, [_vp]),

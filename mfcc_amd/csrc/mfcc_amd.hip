@@ -582,6 +582,33 @@ int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol
   return MFCC_OK;
 }
 
+int mfcc_utt_scalar_norm(const mfcc_layout* layout, float* feats, int64_t feats_ld, int32_t ncol, void* stream) {
+  if (!layout) return fail(MFCC_ERR_INVALID, "mfcc_utt_scalar_norm: null layout");
+  if (ncol < 1 || ncol > 256 || feats_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_utt_scalar_norm: bad shape (1 <= ncol <= 256)");
+  if (layout->n_utts == 0) return MFCC_OK;
+  if (!feats) return fail(MFCC_ERR_INVALID, "mfcc_utt_scalar_norm: null pointer");
+  hipLaunchKernelGGL(mfcc::utt_scalar_norm_kernel, dim3((unsigned)layout->n_utts), dim3(256), 0, (hipStream_t)stream, feats, feats_ld, ncol,
+                     layout->d_frame_off);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_pad_batch(const mfcc_layout* layout, const float* feats, int64_t feats_ld, int32_t ncol, int32_t time_steps, float value,
+                   int32_t pre_pad, int32_t pre_trunc, float* out, void* stream) {
+  if (!layout) return fail(MFCC_ERR_INVALID, "mfcc_pad_batch: null layout");
+  if (ncol < 1 || feats_ld < ncol || time_steps < 1) return fail(MFCC_ERR_INVALID, "mfcc_pad_batch: bad shape");
+  if ((int64_t)time_steps * ncol > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_pad_batch: time_steps * ncol exceeds 2^31-1");
+  if (layout->n_utts == 0) return MFCC_OK;
+  if (layout->n_utts > 65535) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_pad_batch: more than 65535 utterances per call");
+  if (!out || (!feats && layout->total_frames > 0)) return fail(MFCC_ERR_INVALID, "mfcc_pad_batch: null pointer");
+  const int total = time_steps * ncol;
+  const dim3 grid((unsigned)std::max(1, std::min(64, (total + 255) / 256)), (unsigned)layout->n_utts);
+  hipLaunchKernelGGL(mfcc::pad_batch_kernel, grid, dim3(256), 0, (hipStream_t)stream, feats, feats_ld, ncol, layout->d_frame_off, time_steps,
+                     value, pre_pad, pre_trunc, out);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
 /* ---- streaming ------------------------------------------------------------------------- */
 
 int mfcc_stream_create(const mfcc_plan* plan, int32_t n_streams, int32_t max_chunk, int32_t audio_dtype, mfcc_stream** out) {

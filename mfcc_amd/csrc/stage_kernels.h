@@ -223,4 +223,78 @@ __global__ void __launch_bounds__(256) cmvn_apply_kernel(float* __restrict__ x, 
   }
 }
 
+// Per-utterance scalar normalisation (x - mean) / std with mean and population std taken over
+// ALL values of the utterance, every frame and every coefficient (inference_ctc_eri_05.py:291,
+// CTC/ctc_test_1.py:54).  One workgroup per utterance: float64 sums in LDS, then the in-place
+// update (the second read comes from L2).
+__global__ void __launch_bounds__(256) utt_scalar_norm_kernel(float* __restrict__ x, int64_t ld, int ncol,
+                                                              const int64_t* __restrict__ frame_off) {
+  __shared__ double red[2][256];
+  const int u = blockIdx.x;
+  const int64_t r0 = frame_off[u], nr = frame_off[u + 1] - r0;
+  const int64_t total = nr * ncol;
+  float* const base = x + r0 * ld;
+  double s = 0.0, ss = 0.0;
+  {
+    int64_t r = threadIdx.x / ncol;
+    int c = threadIdx.x - (int)r * ncol;
+    const int dr = blockDim.x / ncol, dc = blockDim.x - dr * ncol;
+    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+      const double v = base[r * ld + c];
+      s += v;
+      ss += v * v;
+      r += dr;
+      c += dc;
+      if (c >= ncol) { c -= ncol; ++r; }
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + k];
+      red[1][threadIdx.x] += red[1][threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (total == 0) return;
+  const double mean = red[0][0] / (double)total;
+  const double var = red[1][0] / (double)total - mean * mean;
+  const float m = (float)mean, inv = (float)(1.0 / sqrt(var > 0.0 ? var : 0.0));
+  {
+    int64_t r = threadIdx.x / ncol;
+    int c = threadIdx.x - (int)r * ncol;
+    const int dr = blockDim.x / ncol, dc = blockDim.x - dr * ncol;
+    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+      float* p = base + r * ld + c;
+      *p = (*p - m) * inv;
+      r += dr;
+      c += dc;
+      if (c >= ncol) { c -= ncol; ++r; }
+    }
+  }
+}
+
+// Ragged rows -> dense [B, T, ncol] batch, padded with `value` and truncated to T frames
+// (pad_sequences, CTC/utils.py:71-128; the zero-padded [batch, time_steps, coeffs] arrays of
+// BiLSTM_7.py:82-124).  pre_pad / pre_trunc select 'pre' instead of 'post'.
+__global__ void __launch_bounds__(256) pad_batch_kernel(const float* __restrict__ feats, int64_t ld, int ncol,
+                                                        const int64_t* __restrict__ frame_off, int T, float value,
+                                                        int pre_pad, int pre_trunc, float* __restrict__ out) {
+  const int u = blockIdx.y;
+  const int64_t r0 = frame_off[u];
+  const int nr = (int)(frame_off[u + 1] - r0);
+  const int kept = nr < T ? nr : T;
+  const int src0 = pre_trunc ? nr - kept : 0;  // first source frame kept
+  const int dst0 = pre_pad ? T - kept : 0;     // where it lands
+  const int total = T * ncol;
+  float* const o = out + (int64_t)u * total;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int t = i / ncol, c = i - t * ncol;
+    const int k = t - dst0;
+    o[i] = (k >= 0 && k < kept) ? feats[(r0 + src0 + k) * ld + c] : value;
+  }
+}
+
 }  // namespace mfcc

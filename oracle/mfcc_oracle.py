@@ -333,3 +333,22 @@ def utterance_scalar_norm(feats):
     """(x - mean(x)) / std(x) over ALL elements (inference_ctc_eri_05.py:291)."""
     feats = np.asarray(feats, dtype=np.float64)
     return (feats - np.mean(feats)) / np.std(feats)
+
+
+def pad_sequences(sequences, maxlen=None, padding="post", truncating="post", value=0.0):
+    """pad_sequences of CTC/utils.py:71-128 for lists of [F_i, D] arrays:
+    returns (x[B, maxlen, D] float32, lengths int64[B])."""
+    lengths = np.asarray([len(s) for s in sequences], dtype=np.int64)
+    if maxlen is None:
+        maxlen = int(lengths.max())
+    shape = next((np.asarray(s).shape[1:] for s in sequences if len(s) > 0), ())
+    x = (np.ones((len(sequences), maxlen) + tuple(shape)) * value).astype(np.float32)
+    for i, s in enumerate(sequences):
+        if len(s) == 0:
+            continue
+        trunc = np.asarray(s[-maxlen:] if truncating == "pre" else s[:maxlen], dtype=np.float32)
+        if padding == "post":
+            x[i, :len(trunc)] = trunc
+        else:
+            x[i, -len(trunc):] = trunc
+    return x, lengths

@@ -427,3 +427,98 @@ def test_other_parameterisations(num_bins, numcep, lift, low):
     assert_cep(got, ref, f"nmel={num_bins} numcep={numcep}")
     lm = mfcc_amd.mfcc39(audio, num_bins=num_bins, numcep=numcep, lift_factor=lift, low_freq=low, kind="logmel")
     assert_logmel(lm[:, :num_bins], st["logmel"], "logmel")
+
+
+# --------------------------------------------------------------------------
+# consumers' data plumbing on the device: CTC batch shaping, .pat pipeline, psf-style call
+# --------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_pad_sequences_and_scalar_norm():
+    import mfcc_amd
+    rng = np.random.default_rng(5)
+    counts = [7, 1, 30, 12]
+    seqs = [rng.standard_normal((n, 39)).astype(np.float32) * 5 + 2 for n in counts]
+    packed = torch.from_numpy(np.concatenate(seqs)).cuda()
+    for maxlen in (None, 10, 40):
+        for padding in ("post", "pre"):
+            for truncating in ("post", "pre"):
+                x, lens = mfcc_amd.pad_sequences(packed, counts, maxlen=maxlen, padding=padding, truncating=truncating, value=-1.5)
+                ref, rl = O.pad_sequences(seqs, maxlen, padding, truncating, -1.5)
+                assert np.array_equal(lens, rl)
+                assert np.array_equal(x.cpu().numpy(), ref), (maxlen, padding, truncating)   # a copy: bit-exact
+    with pytest.raises(ValueError):
+        mfcc_amd.pad_sequences(packed, counts, padding="middle")
+    normed = mfcc_amd.utterance_scalar_norm(packed.clone(), counts).cpu().numpy()
+    pos = 0
+    for s in seqs:
+        np.testing.assert_allclose(normed[pos:pos + len(s)], O.utterance_scalar_norm(s), rtol=0, atol=2e-6)
+        pos += len(s)
+
+
+@pytest.mark.gpu
+def test_ctc_feature_batch(golden):
+    import mfcc_amd
+    rng = np.random.default_rng(9)
+    audios = [np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in (4000, 16000, 7003)]
+    x, seq = mfcc_amd.ctc_feature_batch(audios, time_steps=80)
+    x = x.cpu().numpy()
+    assert x.shape == (3, 80, 39)
+    for i, a in enumerate(audios):
+        ref = O.utterance_scalar_norm(O.mfcc39(a, "self5"))      # inference_ctc_eri_05.py:291
+        n = min(80, ref.shape[0])
+        assert seq[i] == ref.shape[0]
+        np.testing.assert_allclose(x[i, :n], ref[:n], rtol=0, atol=2e-4)  # 1e-3 cepstral tolerance / std (~10)
+        assert np.all(x[i, n:] == 0)
+
+
+@pytest.mark.gpu
+def test_pat_pipeline_preprocess_databuffer(golden, tmp_path):
+    from mfcc_amd import datasets as D
+    import mfcc_amd
+    g = golden("stacking.npz")
+    root = str(tmp_path) + "/"
+    names = ["is1c0001_001.pat", "is1c0001_031.pat"]
+    feats = [np.asarray(g[n[:-4] + "_data"]).T.astype(np.float32) for n in names]   # golden data is [C, F]
+    counts = [f.shape[0] for f in feats]
+    D.write_pat_corpus(root, names, torch.from_numpy(np.concatenate(feats)).cuda(), counts)
+    import os
+    os.makedirs(root + D.label_dir, exist_ok=True)
+    for n in names:
+        np.savetxt(root + D.label_dir + n[:-4] + ".txt", np.asarray(g[n[:-4] + "_labels"]))
+        with open(root + D.data_dir + n, "rb") as fh:                     # the writer reproduces the reference's file
+            assert fh.read() == bytes(np.asarray(g[n[:-4] + "_pat_bytes"]).tobytes())
+    old = mfcc_amd.frontend.coeffs
+    try:
+        labels, vecs = D.Preprocess(17, 1, names, root, -11)
+        assert np.array_equal(np.asarray(vecs), np.asarray(g["is1c0001_031_stack17"]))
+        assert np.array_equal(np.asarray(labels), np.asarray(g["is1c0001_031_stacklab17"]))
+        lb, db = D.Databuffer(2, 11, names, root, -11)
+        assert np.array_equal(db, np.concatenate([g["is1c0001_001_stack11"], g["is1c0001_031_stack11"]]))
+        assert np.array_equal(np.asarray(lb), np.concatenate([g["is1c0001_001_stacklab11"], g["is1c0001_031_stacklab11"]]))
+        mb = D.createMinibatchData(16, 11, db)
+        assert mb.shape == (16, 11 * 39) and mb.dtype == np.float64 and np.array_equal(mb, db[:16].astype(np.float64))
+    finally:
+        mfcc_amd.frontend.coeffs = old
+
+
+@pytest.mark.gpu
+def test_psf_style_call_matches_documented_algorithm():
+    from mfcc_amd import psf
+    rng = np.random.default_rng(2)
+    audio = np.clip(rng.standard_normal(8000) * 3000, -32768, 32767).astype(np.int16)
+    audio[3000:3600] = 0                                   # a stretch of digital silence: exact-zero mel bands
+    feat = psf.mfcc(audio, samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=26, nfft=512, lowfreq=0,
+                    highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True)
+    st = O.mfcc39(audio, "self5", return_stages=True)
+    mel = np.exp(st["logmel"])
+    lm = np.log(np.where(mel == 0, O.EPS64, mel))          # the floor the package applies before the log
+    ref = O.dctopt(O.dct_ortho(lm, 13, loop=False), 22)
+    ref[:, 0] = st["loge"]
+    assert np.isfinite(feat).all()
+    assert_cep(feat, ref, "psf.mfcc")
+    d = psf.delta(feat, 2)
+    np.testing.assert_allclose(d, O.delta(feat.astype(np.float64), loop=False), rtol=0, atol=1e-4)
+    full = psf.get_wav_mfcc(audio, 16000)
+    assert full.shape == (feat.shape[0], 39) and np.allclose(full[:, :13], feat, atol=1e-6)
+    with pytest.raises(ValueError):
+        psf.mfcc(audio, highfreq=4000)

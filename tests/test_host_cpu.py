@@ -106,3 +106,19 @@ def test_shard_utterances_balances_frames():
         assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
         frames = [sum(1 + -(-(int(n) - 400) // 160) for n in lengths[a:b]) for a, b in parts]
         assert max(frames) - min(frames) <= 2 * 1000
+
+
+def test_dataset_helpers_follow_the_reference(golden):
+    """Host-only helpers of the .pat pipeline (MLP_5hidlayer_40.py:107-142)."""
+    from mfcc_amd import datasets as D
+    v = D.createRandomvec(3, 10)
+    np.random.seed(3)
+    ref = np.arange(10)
+    np.random.shuffle(ref)
+    assert np.array_equal(v, ref)
+    assert D.randomShuffleData(3, list("abcdefghij")) == [list("abcdefghij")[i] for i in ref]
+    lab = D.createMinibatchLabel(3, 5, [1.0, 5.0, 2.0])
+    assert lab.shape == (3, 5) and lab[0, 0] == 1 and lab[1, 4] == 1 and lab[2, 1] == 1 and lab.sum() == 3
+    x = np.arange(2 * 39, dtype=np.float32).reshape(2, 39)
+    y = D.energy_last(x)
+    assert np.array_equal(y[0, :13], np.r_[1:13, 0]) and np.array_equal(y[0, 13:26], np.r_[14:26, 13])
