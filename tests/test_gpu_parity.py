@@ -14,6 +14,9 @@ Tolerances (float32 kernels vs the float64 reference):
   * cepstra, delta, delta-delta (all 39 columns): 1e-3 ABSOLUTE;
   * integer / copy operations (stacking, .pat round trip): bit exact.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -522,3 +525,26 @@ def test_psf_style_call_matches_documented_algorithm():
     assert full.shape == (feat.shape[0], 39) and np.allclose(full[:, :13], feat, atol=1e-6)
     with pytest.raises(ValueError):
         psf.mfcc(audio, highfreq=4000)
+
+
+@pytest.mark.gpu
+def test_examples_run_like_the_reference_main(golden, tmp_path, monkeypatch, capsys):
+    """examples/ hold the counterparts of the reference's call sites; run them in-process."""
+    import runpy
+    import scipy.io.wavfile as wav
+    g = golden("ldc93s1.npz")
+    path = str(tmp_path / "utt.wav")
+    wav.write(path, 16000, np.asarray(g["audio"], dtype=np.int16))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for variant in ("self5", "self15"):
+        for extra in ([], ["--fused"]):
+            monkeypatch.setattr(sys, "argv", ["mfcc_self5_main.py", path, "--variant", variant, "--pat", str(tmp_path / "o.pat")] + extra)
+            runpy.run_path(os.path.join(root, "examples", "mfcc_self5_main.py"), run_name="__main__")
+            out = np.load(str(tmp_path / f"utt.{variant}.mfcc39.npy"))
+            assert_cep(out, g[f"{variant}_out"], f"example {variant} {extra}")
+    monkeypatch.setattr(sys, "argv", ["stream_chunks.py", path, "--streams", "2"])
+    runpy.run_path(os.path.join(root, "examples", "stream_chunks.py"), run_name="__main__")
+    assert "max |stream - offline|" in capsys.readouterr().out
+    monkeypatch.setattr(sys, "argv", ["ctc_batch.py", path, path, "--time-steps", "300"])
+    runpy.run_path(os.path.join(root, "examples", "ctc_batch.py"), run_name="__main__")
+    assert "(2, 300, 39)" in capsys.readouterr().out
