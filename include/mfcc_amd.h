@@ -69,6 +69,9 @@ typedef struct mfcc_config {
   int32_t window;     /* MFCC_WINDOW_*                                          */
   int32_t floor_mel;  /* 0 = ln of the unfloored mel sum, -inf on silence (mfcc-self5.py:126-127);
                          1 = floor exact zeros to float64 eps first            */
+  int32_t num_fft;    /* 0 = next power of two >= frame size as winfft derives it (mfcc-self5.py:79-84);
+                         otherwise the explicit FFT length of the callers that pass nfft=512
+                         (inference_ctc_eri_05.py:253-257)                     */
 } mfcc_config;
 
 typedef struct mfcc_plan mfcc_plan;     /* immutable constant tables on one device          */

@@ -35,6 +35,7 @@ class MfccConfig(C.Structure):
         ("spectrum", C.c_int32),
         ("window", C.c_int32),
         ("floor_mel", C.c_int32),
+        ("num_fft", C.c_int32),
     ]
 
 

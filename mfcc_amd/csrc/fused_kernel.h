@@ -35,8 +35,20 @@
 
 namespace mfcc {
 
-constexpr int kFrameSize = 400;   // int(16000 * 0.025), mfcc-self5.py:75
-constexpr int kFrameStep = 160;   // int(16000 * 0.010), mfcc-self5.py:76
+// Frame geometry is a compile-time parameter of the kernels.  400/160 is the reference's
+// int(16000 * 0.025) / int(16000 * 0.010) (mfcc-self5.py:75-76); 200/80 is the same 25 ms / 10 ms
+// at 8 kHz with the FFT kept at 512 points, as the reference's CTC scripts ask of their MFCC
+// routine (inference_ctc_eri_05.py:96,253-257: RATE = 8000, nfft=512).
+template <int SIZE, int STEP>
+struct FrameGeom {
+  static constexpr int kSize = SIZE;
+  static constexpr int kStep = STEP;
+  static constexpr int kStageLen = 15 * STEP + SIZE;  // samples staged per 16-frame batch
+};
+typedef FrameGeom<400, 160> Geom16k;
+typedef FrameGeom<200, 80> Geom8k;
+constexpr int kFrameSize = Geom16k::kSize;   // largest supported frame: sizes the LDS carve
+constexpr int kFrameStep = Geom16k::kStep;
 constexpr int kNfft = 512;        // next power of two, mfcc-self5.py:79-84
 constexpr int kNbin = kNfft / 2 + 1;
 constexpr int kBatch = 16;        // frames per batch (4 waves x 4 frames)
@@ -175,13 +187,13 @@ struct StageRegs {
 // zeros by stage_store.  Being branch-free matters: the loads stay in one basic block with the
 // matrix-core section that follows, which lets the compiler wait for the filterbank operands
 // without also waiting for these (younger, HBM-latency) loads.
-template <typename T>
+template <typename T, class G>
 __device__ __forceinline__ void stage_load(const T* buf, int64_t total, int64_t s_off, StageRegs& r, int tb, int tid) {
   // buf/total = the whole audio buffer (total >= 1), s_off = first sample of the utterance
   constexpr int CE = 16 / (int)sizeof(T);  // elements per chunk
   constexpr int NR = sizeof(T) == 2 ? 2 : 3;
   constexpr int64_t kBig = 1 << 24;
-  const T* const b0 = buf + s_off + (int64_t)tb * kFrameStep;  // first sample of the batch
+  const T* const b0 = buf + s_off + (int64_t)tb * G::kStep;  // first sample of the batch
   const int delta = (int)(((uintptr_t)b0 & 15) / sizeof(T));
   const T* const a0 = b0 - delta;                               // aligned chunk 0
   const T* const last = buf + (total - 1);                      // last element of the buffer
@@ -191,7 +203,7 @@ __device__ __forceinline__ void stage_load(const T* buf, int64_t total, int64_t 
   const int64_t hi64 = hi_chunk - a0c, hip64 = last - p0;
   const unsigned hi_el = (unsigned)(hi64 < kBig ? hi64 : kBig), hip_el = (unsigned)(hip64 < kBig ? hip64 : kBig);
   const unsigned lop_el = a0c > buf ? 0u : (unsigned)(buf - a0c) + 1u;  // first offset from p0 inside the buffer
-  const unsigned nchunk = (delta + kStage + CE - 1) / CE;
+  const unsigned nchunk = (delta + G::kStageLen + CE - 1) / CE;
   r.delta = delta;
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
@@ -201,16 +213,16 @@ __device__ __forceinline__ void stage_load(const T* buf, int64_t total, int64_t 
   }
 }
 
-template <typename T>
+template <typename T, class G>
 __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int64_t len, int tb, int tid,
                                             float pre_hi, float pre_lo) {
   constexpr int CE = 16 / (int)sizeof(T);
   constexpr int NR = sizeof(T) == 2 ? 2 : 3;
   constexpr int kBig = 1 << 20;
   const int delta = r.delta;
-  const int64_t rem64 = len - (int64_t)tb * kFrameStep;  // samples of this utterance from the batch start on
+  const int64_t rem64 = len - (int64_t)tb * G::kStep;  // samples of this utterance from the batch start on
   const int i_hi = delta + (rem64 > kBig ? kBig : (int)rem64);
-  const int nchunk = (delta + kStage + CE - 1) / CE;
+  const int nchunk = (delta + G::kStageLen + CE - 1) / CE;
   // interior batch: no utterance start, no utterance end inside the staged range
   const bool interior = tb > 0 && i_hi >= nchunk * CE;
 #pragma unroll
@@ -262,8 +274,8 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int
 }
 
 // NCEP > 0 fixes numcep at compile time (cheap index arithmetic in the epilogue); 0 = runtime.
-// T is the sample type of the audio buffer (int16_t or float).
-template <int OUT, int NCEP, typename T>
+// T is the sample type of the audio buffer (int16_t or float), G the frame geometry.
+template <int OUT, int NCEP, typename T, class G>
 __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(128))) float smem[];
   float* const xbuf = smem;
@@ -316,9 +328,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const int partner_addr = ((lane & 48) | partner_lane(q)) << 2;
 
   StageRegs sr;
-  auto stage_ld = [&](int tb) { stage_load<T>((const T*)p.audio, p.total_elems, s_off, sr, tb, tid); };
+  auto stage_ld = [&](int tb) { stage_load<T, G>((const T*)p.audio, p.total_elems, s_off, sr, tb, tid); };
   auto stage_st = [&](int tb) -> int {
-    stage_store<T>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
+    stage_store<T, G>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
     return sr.delta;
   };
   // floor of the mel energies: 0 = none (ln 0 = -inf as the reference, mfcc-self5.py:125-127)
@@ -343,15 +355,15 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     float bv[kMelSteps];  // B operands of this wave's filterbank k-steps, fetched at the end of the FFT section
     // ---- FFT-512 of 4 frames per wave, 16 lanes per frame -----------------------------
     {
-      const float* fa = abuf + delta + fb * kFrameStep;
+      const float* fa = abuf + delta + fb * G::kStep;
       cf x[16];
       if (delta & 1) {  // odd sample offset: the (x[2n], x[2n+1]) pairs are not 8-byte aligned in LDS
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
           const int n = 16 * n1 + q;
-          if (2 * (16 * n1) < kFrameSize) {
-            const int nn = min(n, kFrameSize / 2 - 1);
-            const float ok = 2 * n + 1 < kFrameSize ? 1.f : 0.f;
+          if (2 * (16 * n1) < G::kSize) {
+            const int nn = min(n, G::kSize / 2 - 1);
+            const float ok = 2 * n + 1 < G::kSize ? 1.f : 0.f;
             x[n1] = mk(fa[2 * nn] * ok, fa[2 * nn + 1] * ok);
           } else {
             x[n1] = mk(0.f, 0.f);
@@ -362,11 +374,11 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
           const int n = 16 * n1 + q;  // complex sample index: (x[2n], x[2n+1])
-          if (2 * (16 * n1 + 15) + 1 < kFrameSize) {
+          if (2 * (16 * n1 + 15) + 1 < G::kSize) {
             x[n1] = fa2[n];
-          } else if (2 * (16 * n1) < kFrameSize) {
-            const float ok = 2 * n + 1 < kFrameSize ? 1.f : 0.f;  // staged samples are finite: 0 * v = 0
-            x[n1] = fa2[min(n, kFrameSize / 2 - 1)] * mk(ok, ok);
+          } else if (2 * (16 * n1) < G::kSize) {
+            const float ok = 2 * n + 1 < G::kSize ? 1.f : 0.f;  // staged samples are finite: 0 * v = 0
+            x[n1] = fa2[min(n, G::kSize / 2 - 1)] * mk(ok, ok);
           } else {
             x[n1] = mk(0.f, 0.f);
           }
@@ -374,11 +386,11 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       }
       if (window) {
         // all window loads first (they hit L1/L2), then the products: one wait instead of 13
-        cf wv[(kFrameSize + 31) / 32];
+        cf wv[(G::kSize + 31) / 32];
 #pragma unroll
-        for (int n1 = 0; n1 < (kFrameSize + 31) / 32; ++n1) wv[n1] = mk(window[2 * (16 * n1 + q)], window[2 * (16 * n1 + q) + 1]);
+        for (int n1 = 0; n1 < (G::kSize + 31) / 32; ++n1) wv[n1] = mk(window[2 * (16 * n1 + q)], window[2 * (16 * n1 + q) + 1]);
 #pragma unroll
-        for (int n1 = 0; n1 < (kFrameSize + 31) / 32; ++n1) x[n1] = x[n1] * wv[n1];
+        for (int n1 = 0; n1 < (G::kSize + 31) / 32; ++n1) x[n1] = x[n1] * wv[n1];
       }
       // stage-1 twiddles of this lane: read now (their latency hides under the first 16-point
       // transform); reading them between the exchange writes would serialise on LDS round trips

@@ -105,10 +105,16 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
   const dim3 grid((unsigned)n_tiles), block(256);
   const size_t smem = mfcc::kSmemFloats * sizeof(float) + MFCC_EXTRA_SMEM;
   const bool c13 = plan->cfg.numcep == 13;
-#define MFCC_LAUNCH(OUT, NCEP)                                                                               \
+  const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
+#define MFCC_LAUNCH_G(OUT, NCEP, G)                                                                          \
   do {                                                                                                       \
-    if (i16) hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, int16_t>), grid, block, smem, st, fp);        \
-    else hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, float>), grid, block, smem, st, fp);              \
+    if (i16) hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, int16_t, G>), grid, block, smem, st, fp);     \
+    else hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, float, G>), grid, block, smem, st, fp);           \
+  } while (0)
+#define MFCC_LAUNCH(OUT, NCEP)                                 \
+  do {                                                         \
+    if (g8k) MFCC_LAUNCH_G(OUT, NCEP, mfcc::Geom8k);           \
+    else MFCC_LAUNCH_G(OUT, NCEP, mfcc::Geom16k);              \
   } while (0)
   switch (out_kind) {
     case MFCC_OUT_MFCC39:
@@ -123,6 +129,7 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     case MFCC_OUT_SPEC: MFCC_LAUNCH(mfcc::kOutSpec, 0); break;
     case MFCC_OUT_LOGSPEC: MFCC_LAUNCH(mfcc::kOutLogspec, 0); break;
   }
+#undef MFCC_LAUNCH_G
 #undef MFCC_LAUNCH
 }
 
@@ -147,6 +154,7 @@ void mfcc_config_default(mfcc_config* cfg) {
   cfg->spectrum = MFCC_SPECTRUM_POWER;
   cfg->window = MFCC_WINDOW_NONE;
   cfg->floor_mel = 0;
+  cfg->num_fft = 0;
 }
 
 int mfcc_melbank_host(double fs, int32_t numbins, double lowfreq, int32_t num_fft, double* out_host) {
@@ -173,10 +181,13 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   *out = nullptr;
   int32_t size, step, nfft;
   mfcc::frame_geometry(cfg->fs, cfg->frame_time, cfg->step_time, &size, &step, &nfft);
-  if (size != mfcc::kFrameSize || step != mfcc::kFrameStep || nfft != mfcc::kNfft)
+  if (cfg->num_fft != 0) nfft = cfg->num_fft;
+  const bool g16k = size == mfcc::Geom16k::kSize && step == mfcc::Geom16k::kStep;
+  const bool g8k = size == mfcc::Geom8k::kSize && step == mfcc::Geom8k::kStep;
+  if (!(g16k || g8k) || nfft != mfcc::kNfft)
     return fail(MFCC_ERR_UNSUPPORTED,
                 "framing %d/%d samples, %d-point FFT: the gfx950 kernels are built for 400/160/512 "
-                "(fs=16000, 25 ms / 10 ms)", size, step, nfft);
+                "(fs=16000, 25 ms / 10 ms) and 200/80/512 (fs=8000 with num_fft=512)", size, step, nfft);
   if (cfg->num_bins < 1 || cfg->num_bins > mfcc::kMaxMel)
     return fail(MFCC_ERR_UNSUPPORTED, "num_bins=%d outside 1..%d", cfg->num_bins, mfcc::kMaxMel);
   if (cfg->numcep < 1 || cfg->numcep > mfcc::kMaxCep || cfg->numcep > cfg->num_bins)

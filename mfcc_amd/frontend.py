@@ -110,7 +110,7 @@ class Plan:
 
     def __init__(self, fs=16000, frame_time=25, step_time=10, num_bins=26, low_freq=0, numcep=13,
                  lift_factor=22, pad_fac=2, preemph=0.97, spectrum="power", window=None, floor_mel=False,
-                 device=None):
+                 num_fft=None, device=None):
         self.device = _device(device)
         lib = capi.load()
         cfg = capi.MfccConfig()
@@ -127,6 +127,7 @@ class Plan:
             raise ValueError("window must be None or 'hamming'")
         cfg.window = capi.WINDOW_NONE if window is None else capi.WINDOW_HAMMING
         cfg.floor_mel = 1 if floor_mel else 0
+        cfg.num_fft = 0 if num_fft is None else int(num_fft)   # None: next power of two >= frame size (winfft)
         self.cfg = cfg
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -260,7 +261,7 @@ class MFCC:
 
 def mfcc39(audio, lengths=None, fs=16000, frame_time=25, step_time=10, num_bins=26, low_freq=0, numcep=13,
            lift_factor=22, pad_fac=2, preemph=0.97, spectrum="power", window=None, floor_mel=False, out=None,
-           kind="mfcc39"):
+           kind="mfcc39", num_fft=None):
     """int16/float audio -> float32 [sum F, 39] = [c0=lnE, c1..c12 | delta | delta-delta]
     (the row layout of spectrograms(), mfcc-self5.py:181-186).  ``audio`` is one utterance
     [L], a dense batch [B, L], or a packed batch [sum L] with ``lengths``."""
@@ -268,7 +269,7 @@ def mfcc39(audio, lengths=None, fs=16000, frame_time=25, step_time=10, num_bins=
     fe.plan = get_plan(None if not isinstance(audio, torch.Tensor) or not audio.is_cuda else audio.device,
                        fs=fs, frame_time=frame_time, step_time=step_time, num_bins=num_bins, low_freq=low_freq,
                        numcep=numcep, lift_factor=lift_factor, pad_fac=pad_fac, preemph=preemph, spectrum=spectrum,
-                       window=window, floor_mel=floor_mel)
+                       window=window, floor_mel=floor_mel, num_fft=num_fft)
     fe._layouts = _layout_cache.setdefault(id(fe.plan), {})
     return fe(audio, lengths, out=out, kind=kind)
 
@@ -353,7 +354,9 @@ class StreamingMFCC:
             out = self._out()
         k = C.c_int32(0)
         with torch.cuda.device(self.plan.device):
-            capi.check(capi.load().mfcc_stream_push(self._h, _ptr(t), t.stride(0) if t.shape[1] else 0, t.shape[1],
+            # a single row may carry any stride in its size-1 dimension
+            ld = max(t.stride(0), t.shape[1]) if self.n_streams == 1 else t.stride(0)
+            capi.check(capi.load().mfcc_stream_push(self._h, _ptr(t), ld, t.shape[1],
                                                     _ptr(out), out.stride(0), out.stride(1), C.byref(k), _stream_ptr()))
         return _ret(out[:, :k.value], was_numpy)
 

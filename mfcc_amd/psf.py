@@ -11,8 +11,8 @@ The package itself is not available to check against, so parity with it is UNPIN
 checked is the documented algorithm, which is the numpy routine of mfcc-self5.py with two
 differences: mel energies that are exactly zero are floored to eps before the log (the numpy
 routine discards that floor, mfcc-self5.py:126-127), and ``appendEnergy=False`` keeps the DCT's
-own c0.  Supported geometry is what the gfx950 kernels are built for: 16 kHz, 25 ms / 10 ms,
-nfft 512, highfreq = samplerate / 2.
+own c0.  Supported geometry is what the gfx950 kernels are built for: 25 ms / 10 ms frames at
+16 kHz or at 8 kHz (RATE = 8000 in inference_ctc_eri_05.py:96), nfft 512, highfreq = samplerate / 2.
 """
 from __future__ import annotations
 
@@ -36,7 +36,7 @@ def mfcc(signal, samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=
         raise ValueError("appendEnergy=False is not implemented (c0 is always ln of the frame energy)")
     return F.mfcc39(signal, fs=samplerate, frame_time=winlen * 1000, step_time=winstep * 1000, num_bins=nfilt,
                     low_freq=lowfreq, numcep=numcep, lift_factor=ceplifter, preemph=preemph if preemph else None,
-                    spectrum="power", floor_mel=True, kind="static")
+                    spectrum="power", floor_mel=True, kind="static", num_fft=nfft)
 
 
 def delta(feat, N):
@@ -50,4 +50,4 @@ def delta(feat, N):
 def get_wav_mfcc(audio, fs=16000):
     """get_wav_mfcc of inference_ctc_eri_05.py:245-263 for an already loaded signal:
     [mfcc | delta | delta-delta] = [F, 39] in one fused launch."""
-    return F.mfcc39(audio, fs=fs, floor_mel=True)
+    return F.mfcc39(audio, fs=fs, floor_mel=True, num_fft=512)

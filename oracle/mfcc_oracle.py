@@ -79,13 +79,17 @@ def preemphasis(signal, coeff=0.97):
     return out
 
 
-def winfft(audio, fs=FS, frame_time=FRAME_TIME, step_time=STEP_TIME, loop=True):
+def winfft(audio, fs=FS, frame_time=FRAME_TIME, step_time=STEP_TIME, loop=True, num_fft=None):
     """Framing (no window is applied, self5:95) + rFFT + |X| and |X|^2/nfft.
 
     Returns (mag[F,K], pow[F,K], hamming_window, num_fft)   (self5:70-100).
+    ``num_fft`` overrides the derived FFT length, for callers that pass nfft=512 to their MFCC
+    routine at 8 kHz (inference_ctc_eri_05.py:253-257); the reference's winfft has no such argument.
     """
     audio = np.asarray(audio)
     size, step, nfft = frame_geometry(fs, frame_time, step_time)
+    if num_fft is not None:
+        nfft = int(num_fft)
     n_frames = frame_count(audio.shape[0], size, step)
     padded_len = (n_frames - 1) * step + size
     padded = np.zeros(padded_len, dtype=np.float64)  # self5:89-90 zero tail
@@ -230,11 +234,11 @@ def spectrograms(cep, d, dd):
 # --------------------------------------------------------------------------
 def mfcc39(audio, variant="self5", fs=FS, frame_time=FRAME_TIME, step_time=STEP_TIME,
            num_bins=NUM_BINS, low_freq=LOW_FREQ, lift_factor=LIFT_FACTOR, loop=True,
-           return_stages=False):
+           return_stages=False, num_fft=None):
     cfg = VARIANTS[variant]
     audio = np.asarray(audio)
     sig = preemphasis(audio, cfg["preemph"]) if cfg["preemph"] is not None else audio
-    mag, pw, _win, nfft = winfft(sig, fs, frame_time, step_time, loop=loop)
+    mag, pw, _win, nfft = winfft(sig, fs, frame_time, step_time, loop=loop, num_fft=num_fft)
     bank = melbanks(fs, num_bins, low_freq, nfft)
     spec = pw if cfg["spectrum"] == "power" else mag
     logmel, loge = melspec(spec, bank, loop=loop)

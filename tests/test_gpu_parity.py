@@ -548,3 +548,30 @@ def test_examples_run_like_the_reference_main(golden, tmp_path, monkeypatch, cap
     monkeypatch.setattr(sys, "argv", ["ctc_batch.py", path, path, "--time-steps", "300"])
     runpy.run_path(os.path.join(root, "examples", "ctc_batch.py"), run_name="__main__")
     assert "(2, 300, 39)" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_8khz_geometry_with_512_point_fft(variant):
+    """25 ms / 10 ms at 8 kHz = 200/80-sample frames, FFT kept at 512 points (the CTC scripts' call,
+    inference_ctc_eri_05.py:96,253-257).  Checked against the restatement with num_fft=512."""
+    import mfcc_amd
+    rng = np.random.default_rng(21)
+    lengths = [1, 199, 200, 201, 281, 8000, 12345]
+    audios = [np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths]
+    fe = mfcc_amd.MFCC(variant, fs=8000, num_fft=512)
+    assert (fe.plan.frame_size, fe.plan.frame_step, fe.plan.num_fft) == (200, 80, 512)
+    out = fe(np.concatenate(audios), lengths=lengths)
+    pos = 0
+    for a in audios:
+        ref = O.mfcc39(a, variant, fs=8000, num_fft=512)
+        assert_cep(out[pos:pos + ref.shape[0]], ref, f"8 kHz L={len(a)}")
+        pos += ref.shape[0]
+    assert pos == out.shape[0]
+    # streaming at 8 kHz
+    s = mfcc_amd.StreamingMFCC(variant, n_streams=1, max_chunk=400, fs=8000, num_fft=512)
+    got = _stream_all(s, torch.from_numpy(audios[-1][None, :]).cuda(), [80, 333]).cpu().numpy()[0]
+    assert_cep(got, O.mfcc39(audios[-1], variant, fs=8000, num_fft=512), "8 kHz stream")
+    # the reference's own winfft would take a 256-point FFT at this frame size: not built
+    with pytest.raises(mfcc_amd.frontend.capi.MfccError):
+        mfcc_amd.MFCC(variant, fs=8000)
