@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       for (int idx = tid; idx < nvalid * kNbin; idx += 256) {
         const int f = idx / kNbin, k = idx - f * kNbin;
         float v = xbuf[f * kSlot + k] * scale;
-        if (OUT == kOutLogspec) v = logf(v);
+        if (OUT == kOutLogspec) v = fast_ln(v);  // ln 0 = -inf as np.log
         out_t0[(tb - t0 + f) * ld + k] = v;
       }
       if (more) delta = stage_st(tb + kBatch);

@@ -558,8 +558,14 @@ int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t fe
   if (layout->total_frames == 0) return MFCC_OK;
   if (!feats || !out) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: null pointer");
   if (layout->total_frames > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_stack_context: more than 2^31-1 rows per call");
-  hipLaunchKernelGGL(mfcc::stack_context_kernel, dim3((unsigned)layout->total_frames), dim3(256), 0, (hipStream_t)stream, feats, feats_ld,
-                     ncol, framenum, layout->d_frame_off, layout->d_row_utt, out);
+  if (((uintptr_t)out & 15) == 0 && (int64_t)framenum * ncol * mfcc::kStackRows < (1 << 24)) {
+    const int64_t nblk = ((layout->total_frames + mfcc::kStackRows - 1) / mfcc::kStackRows + 7) / 8 * 8;  // whole rounds over the 8 XCDs
+    hipLaunchKernelGGL(mfcc::stack_context_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, feats, feats_ld, ncol,
+                       framenum, layout->d_frame_off, layout->d_row_utt, out, layout->total_frames);
+  } else {
+    hipLaunchKernelGGL(mfcc::stack_context_kernel, dim3((unsigned)layout->total_frames), dim3(256), 0, (hipStream_t)stream, feats, feats_ld,
+                       ncol, framenum, layout->d_frame_off, layout->d_row_utt, out);
+  }
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
 }

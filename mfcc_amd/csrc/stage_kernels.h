@@ -162,6 +162,85 @@ __global__ void __launch_bounds__(256) stack_context_kernel(const float* __restr
   }
 }
 
+// The same operation for a 16-byte aligned output: a workgroup owns kStackRows consecutive output
+// rows, i.e. one contiguous, 16-byte aligned run of kStackRows*N*C floats (8 rows of any width
+// are a multiple of 4 floats), and streams it out with aligned non-temporal 16-byte stores, so
+// there are few, long workgroups and no per-row alignment fix-ups.  Utterance bounds of the rows
+// sit in LDS; (row, frame, column) of each thread's position advance incrementally.
+constexpr int kStackRows = 8;
+__global__ void __launch_bounds__(256) stack_context_rows_kernel(const float* __restrict__ feats, int64_t feats_ld, int ncol,
+                                                                 int framenum, const int64_t* __restrict__ frame_off,
+                                                                 const int32_t* __restrict__ row_utt, float* __restrict__ out,
+                                                                 int64_t total_rows) {
+  __shared__ int64_t lo[kStackRows], hi[kStackRows];
+  // Workgroups are handed to the 8 XCDs round-robin and each XCD has its own L2: give every XCD
+  // one contiguous eighth of the rows, so that the N-fold re-read of a source row is served by
+  // the L2 that fetched it instead of by the fabric eight times over.
+  const int64_t nblk = (total_rows + kStackRows - 1) / kStackRows;
+  const int64_t per_xcd = (nblk + 7) / 8;
+  const int64_t blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (blk >= nblk) return;
+  const int64_t row0 = blk * kStackRows;
+  const int nrows = (int)(total_rows - row0 < kStackRows ? total_rows - row0 : kStackRows);
+  if ((int)threadIdx.x < nrows) {
+    const int u = row_utt[row0 + threadIdx.x];
+    lo[threadIdx.x] = frame_off[u];
+    hi[threadIdx.x] = frame_off[u + 1] - 1;
+  }
+  __syncthreads();
+  const int half = (framenum - 1) / 2;
+  const int width = framenum * ncol;
+  const int total = nrows * width;
+  const int nvec = total >> 2;
+  float* const o = out + row0 * (int64_t)width;
+  const float rcp = 1.0f / (float)ncol;
+  auto src = [&](int r, int f) {
+    int64_t t = row0 + r + f - half;
+    t = t < lo[r] ? lo[r] : (t > hi[r] ? hi[r] : t);
+    return feats + t * feats_ld;
+  };
+  // position of this thread's first element: row r, offset rem inside the row
+  int i = 4 * (int)threadIdx.x;
+  int r = i / width, rem = i - r * width;
+  const int di = 4 * 256, dr = di / width, drem = di - dr * width;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    int f = (int)((float)rem * rcp);  // rem / ncol, fixed up below (rem < 2^24)
+    if (f * ncol > rem) --f;
+    if ((f + 1) * ncol <= rem) ++f;
+    const int c = rem - f * ncol;
+    float val[4];
+    if (c + 3 < ncol) {
+      // one 16-byte load at 4-byte alignment (global memory accepts it; an odd row width puts
+      // the source anywhere)
+      typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+      const f32x4_u q4 = *(const f32x4_u*)(src(r, f) + c);
+      val[0] = q4.x; val[1] = q4.y; val[2] = q4.z; val[3] = q4.w;
+    } else {
+      int rr = r, ff = f, cc = c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        val[j] = src(rr, ff)[cc];
+        if (++cc == ncol) {
+          cc = 0;
+          if (++ff == framenum) { ff = 0; ++rr; }
+        }
+        if (rr >= nrows) rr = nrows - 1;  // past the last element of the run: value unused
+      }
+    }
+    f32x4_t pk = {val[0], val[1], val[2], val[3]};
+    __builtin_nontemporal_store(pk, (f32x4_t*)(o + 4 * (int64_t)v));  // plain stores measured 40 % slower here
+    r += dr;
+    rem += drem;
+    if (rem >= width) { rem -= width; ++r; }
+  }
+  if ((int)threadIdx.x < total - 4 * nvec) {  // fewer than 4 floats at the very end of the array
+    const int e = 4 * nvec + threadIdx.x;
+    const int rr = e / width, re = e - rr * width, ff = re / ncol;
+    o[e] = src(rr, ff)[re - ff * ncol];
+  }
+}
+
 // sums[0] += rows, sums[1+c] += sum x, sums[1+D+c] += sum x^2, all in float64.
 // Each workgroup reduces a slab of rows in registers/LDS and issues one atomic per column.
 __global__ void cmvn_accumulate_kernel(const float* __restrict__ x, int64_t ld, int64_t n_rows, int ncol,

@@ -284,6 +284,9 @@ def spectrum257(audio, lengths=None, preemph=0.97, spectrum="power", window=None
                   kind="logspec" if log else "spec")
 
 
+_frame_layouts = {}
+
+
 def stack_context(feats, framenum, frame_counts=None, out=None):
     """[sum F, C] -> [sum F, framenum*C], frame-major with edge replication per utterance:
     out[t, f*C + c] = feats[clamp(t + f - (N-1)//2), c]   (padUtterance + slidingWin,
@@ -298,7 +301,13 @@ def stack_context(feats, framenum, frame_counts=None, out=None):
     if int(np.sum(frame_counts)) != n:
         raise ValueError("frame_counts do not add up to the number of rows")
     plan = get_plan(t.device)
-    lay = Layout.from_frame_counts(plan, frame_counts)
+    fc = np.ascontiguousarray(np.asarray(frame_counts, dtype=np.int64).reshape(-1))
+    key = (id(plan), fc.tobytes())
+    lay = _frame_layouts.get(key)
+    if lay is None:   # building a layout uploads offset tables: keep it for repeated batch shapes
+        if len(_frame_layouts) > 16:
+            _frame_layouts.clear()
+        lay = _frame_layouts[key] = Layout.from_frame_counts(plan, fc)
     if out is None:
         out = torch.empty((n, framenum * c), dtype=torch.float32, device=t.device)
     elif out.shape != (n, framenum * c) or out.dtype != torch.float32 or not out.is_contiguous():
