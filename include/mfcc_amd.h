@@ -72,6 +72,11 @@ typedef struct mfcc_config {
   int32_t num_fft;    /* 0 = next power of two >= frame size as winfft derives it (mfcc-self5.py:79-84);
                          otherwise the explicit FFT length of the callers that pass nfft=512
                          (inference_ctc_eri_05.py:253-257)                     */
+  int32_t frame_rule; /* 0 = zero-pad the last frame: F = 1 + ceil(max(0, L - size) / step)  (winfft, mfcc-self5.py:85-92);
+                         1 = complete frames only: F = max(0, fix((L - (size - step)) / step))
+                             (spec_anal, anal_recog_nn_liste.m:503)                     */
+  double log_floor;   /* MFCC_OUT_LOGSPEC takes ln(max(v, log_floor)) when > 0: the log(max(|X|, 1)) of
+                         spec_anal, anal_recog_nn_liste.m:529; 0 = plain ln            */
 } mfcc_config;
 
 typedef struct mfcc_plan mfcc_plan;     /* immutable constant tables on one device          */
@@ -135,6 +140,13 @@ int mfcc_delta(const float* feats, int64_t n_frames, int32_t ncol, int32_t pad_f
  * spectrograms' concatenation (:184-185) are built from it */
 int mfcc_copy_cols(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t n_rows, int32_t ncol,
                    void* stream);
+
+/* Centred FIR filter per utterance of the layout: out[n] = sum_k taps[k] * x[n + delay - k],
+ * samples outside the utterance count as zero.  With the 15 taps of initdft.bpre and delay 7
+ * this is spec_anal's pre-emphasis, filter() followed by the group-delay shift
+ * (anal_recog_nn_liste.m:56-57, :511-516).  taps_host: at most 32 coefficients, read at call time. */
+int mfcc_fir(const mfcc_layout* layout, const void* audio, int32_t audio_dtype, const float* taps_host, int32_t ntaps,
+             int32_t delay, float* out, void* stream);
 
 /* ---- context stacking ----------------------------------------------------------
  * padUtterance + slidingWin, MLP_5hidlayer_40.py:70-105:

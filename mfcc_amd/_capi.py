@@ -36,6 +36,8 @@ class MfccConfig(C.Structure):
         ("window", C.c_int32),
         ("floor_mel", C.c_int32),
         ("num_fft", C.c_int32),
+        ("frame_rule", C.c_int32),
+        ("log_floor", C.c_double),
     ]
 
 
@@ -70,6 +72,7 @@ SIGNATURES = {
     "mfcc_dct": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "mfcc_lifter": (C.c_int, [_vp, _i64, _i32, _dbl, _vp, _vp]),
     "mfcc_delta": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "mfcc_fir": (C.c_int, [_vp, _vp, _i32, C.POINTER(C.c_float), _i32, _i32, _vp, _vp]),
     "mfcc_copy_cols": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "mfcc_stack_context": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "mfcc_cmvn_accumulate": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),

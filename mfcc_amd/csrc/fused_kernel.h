@@ -117,6 +117,7 @@ struct PlanConst {
   int32_t spectrum;       // 0 power, 1 magnitude
   int32_t floor_mel;
   float spec_scale;       // 1/(4*nfft) for power, 1/2 for magnitude (both exact powers of two)
+  float log_floor;        // log-spectrum output: ln(max(v, log_floor)) when > 0 (anal_recog_nn_liste.m:529)
 };
 
 struct FusedParams {
@@ -479,12 +480,12 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 
     if (OUT == kOutSpec || OUT == kOutLogspec) {
       const int nvalid = min(kBatch, s_hi - tb);
-      const float scale = pc->spec_scale;
+      const float scale = pc->spec_scale, lfloor = pc->log_floor;
       stage_ld(tb + kBatch);
       for (int idx = tid; idx < nvalid * kNbin; idx += 256) {
         const int f = idx / kNbin, k = idx - f * kNbin;
         float v = xbuf[f * kSlot + k] * scale;
-        if (OUT == kOutLogspec) v = fast_ln(v);  // ln 0 = -inf as np.log
+        if (OUT == kOutLogspec) v = fast_ln(fmaxf(v, lfloor));  // floor 0 = none: ln 0 = -inf as np.log
         out_t0[(tb - t0 + f) * ld + k] = v;
       }
       if (more) delta = stage_st(tb + kBatch);

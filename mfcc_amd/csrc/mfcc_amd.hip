@@ -155,6 +155,8 @@ void mfcc_config_default(mfcc_config* cfg) {
   cfg->window = MFCC_WINDOW_NONE;
   cfg->floor_mel = 0;
   cfg->num_fft = 0;
+  cfg->frame_rule = 0;
+  cfg->log_floor = 0.0;
 }
 
 int mfcc_melbank_host(double fs, int32_t numbins, double lowfreq, int32_t num_fft, double* out_host) {
@@ -314,6 +316,7 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   pch.spectrum = cfg->spectrum;
   pch.floor_mel = cfg->floor_mel;
   pch.spec_scale = p->spec_scale;
+  pch.log_floor = (float)cfg->log_floor;
   if ((rc = upload(std::vector<mfcc::PlanConst>(1, pch), &p->pc))) {
     mfcc_plan_destroy(p);
     return rc;
@@ -375,7 +378,9 @@ int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64
       return fail(MFCC_ERR_INVALID, "utterance %lld has length %lld (the reference needs >= 1 sample: signal[0], mfcc-self5.py:68)",
                   (long long)u, (long long)len);
     }
-    const int64_t nf = mfcc::frames_for_length(len, plan->frame_size, plan->frame_step);
+    const int64_t nf = plan->cfg.frame_rule == 1
+                           ? std::max<int64_t>(0, (len - (plan->frame_size - plan->frame_step)) / plan->frame_step)
+                           : mfcc::frames_for_length(len, plan->frame_size, plan->frame_step);
     if (nf > INT32_MAX) {
       delete l;
       return fail(MFCC_ERR_UNSUPPORTED, "utterance %lld has more than 2^31-1 frames", (long long)u);
@@ -449,7 +454,7 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   const int32_t width = mfcc_out_width(plan, out_kind);
   if (width < 0) return width;
   if (out_ld < width) return fail(MFCC_ERR_INVALID, "out_ld=%lld < row width %d", (long long)out_ld, width);
-  if (layout->n_utts == 0) return MFCC_OK;
+  if (layout->n_utts == 0 || layout->n_tiles == 0) return MFCC_OK;
   if (!out || (!audio && layout->total_samples > 0)) return fail(MFCC_ERR_INVALID, "mfcc_forward: null device pointer");
 
   mfcc::FusedParams fp;
@@ -549,6 +554,30 @@ int mfcc_copy_cols(const float* src, int64_t src_ld, float* dst, int64_t dst_ld,
   return MFCC_OK;
 }
 
+int mfcc_fir(const mfcc_layout* layout, const void* audio, int32_t audio_dtype, const float* taps_host, int32_t ntaps, int32_t delay,
+             float* out, void* stream) {
+  if (!layout || !taps_host) return fail(MFCC_ERR_INVALID, "mfcc_fir: null argument");
+  if (ntaps < 1 || ntaps > 32 || delay < 0 || delay >= ntaps) return fail(MFCC_ERR_INVALID, "mfcc_fir: 1..32 taps, 0 <= delay < ntaps");
+  if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
+  if (layout->total_samples == 0) return MFCC_OK;
+  if (!audio || !out) return fail(MFCC_ERR_INVALID, "mfcc_fir: null device pointer");
+  mfcc::FirTaps t;
+  memset(&t, 0, sizeof(t));
+  memcpy(t.w, taps_host, ntaps * sizeof(float));
+  t.n = ntaps;
+  t.delay = delay;
+  const int64_t nblk = (layout->total_samples + 1023) / 1024;
+  if (nblk > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_fir: too many samples per call");
+  if (audio_dtype == MFCC_AUDIO_I16)
+    hipLaunchKernelGGL(mfcc::fir_kernel<int16_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const int16_t*)audio,
+                       layout->d_sample_off, (int)layout->n_utts, layout->total_samples, t, out);
+  else
+    hipLaunchKernelGGL(mfcc::fir_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const float*)audio,
+                       layout->d_sample_off, (int)layout->n_utts, layout->total_samples, t, out);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
 int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t feats_ld, int32_t ncol, int32_t framenum, float* out,
                        void* stream) {
   if (!layout) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: null layout");
@@ -635,6 +664,7 @@ int mfcc_stream_create(const mfcc_plan* plan, int32_t n_streams, int32_t max_chu
   if (max_chunk < 1 || max_chunk > (1 << 24)) return fail(MFCC_ERR_INVALID, "max_chunk=%d outside 1..2^24", max_chunk);
   if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
   if (plan->cfg.pad_fac != 2) return fail(MFCC_ERR_UNSUPPORTED, "streaming implements pad_fac=2");
+  if (plan->cfg.frame_rule != 0) return fail(MFCC_ERR_UNSUPPORTED, "streaming implements frame_rule=0 (zero-padded last frame)");
   HIP_TRY(hipSetDevice(plan->device));
   mfcc_stream* s = new (std::nothrow) mfcc_stream();
   if (!s) return fail(MFCC_ERR_NOMEM, "mfcc_stream_create: out of host memory");

@@ -104,6 +104,43 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int64_t src_ld, 
   dst[r * dst_ld + c] = src[r * src_ld + c];
 }
 
+// Centred FIR per utterance: out[n] = sum_k taps[k] * x[n + delay - k], zero outside the
+// utterance (filter() + group-delay shift of spec_anal, anal_recog_nn_liste.m:511-516).  A block
+// covers 1024 consecutive samples of the packed buffer; its first utterance is found by bisection
+// once, threads then step forward over the (rare) boundaries inside the block.
+struct FirTaps {
+  float w[32];
+  int32_t n, delay;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) fir_kernel(const T* __restrict__ x, const int64_t* __restrict__ sample_off, int n_utts,
+                                                  int64_t total, const FirTaps taps, float* __restrict__ out) {
+  __shared__ int u_first;
+  const int64_t base = (int64_t)blockIdx.x * 1024;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n_utts - 1;  // last u with sample_off[u] <= base
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (sample_off[mid] <= base) lo = mid; else hi = mid - 1;
+    }
+    u_first = lo;
+  }
+  __syncthreads();
+  int u = u_first;
+  for (int j = 0; j < 4; ++j) {
+    const int64_t n = base + threadIdx.x + 256 * j;
+    if (n >= total) return;
+    while (n >= sample_off[u + 1]) ++u;  // skips empty utterances too
+    const int64_t s0 = sample_off[u], s1 = sample_off[u + 1];
+    float acc = 0.f;
+    for (int k = 0; k < taps.n; ++k) {
+      const int64_t m = n + taps.delay - k;
+      if (m >= s0 && m < s1) acc = fmaf(taps.w[k], (float)x[m], acc);
+    }
+    out[n] = acc;
+  }
+}
+
 // Context stacking, MLP_5hidlayer_40.py:70-105: one workgroup per output row t of
 // utterance u; out[t, f*C + c] = feats[clamp(t + f - h), c].  The write of N*C contiguous
 // floats per row is the traffic that matters (N x the read, which stays in L2): the row is

@@ -110,7 +110,7 @@ class Plan:
 
     def __init__(self, fs=16000, frame_time=25, step_time=10, num_bins=26, low_freq=0, numcep=13,
                  lift_factor=22, pad_fac=2, preemph=0.97, spectrum="power", window=None, floor_mel=False,
-                 num_fft=None, device=None):
+                 num_fft=None, frame_rule="pad", log_floor=0.0, device=None):
         self.device = _device(device)
         lib = capi.load()
         cfg = capi.MfccConfig()
@@ -128,6 +128,10 @@ class Plan:
         cfg.window = capi.WINDOW_NONE if window is None else capi.WINDOW_HAMMING
         cfg.floor_mel = 1 if floor_mel else 0
         cfg.num_fft = 0 if num_fft is None else int(num_fft)   # None: next power of two >= frame size (winfft)
+        if frame_rule not in ("pad", "complete"):
+            raise ValueError("frame_rule must be 'pad' (winfft) or 'complete' (spec_anal)")
+        cfg.frame_rule = 0 if frame_rule == "pad" else 1
+        cfg.log_floor = float(log_floor)
         self.cfg = cfg
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -141,6 +145,8 @@ class Plan:
         return capi.check(capi.load().mfcc_out_width(self._h, _OUT_KINDS[kind]))
 
     def frames_for_length(self, n):
+        if self.cfg.frame_rule == 1:   # complete frames only (anal_recog_nn_liste.m:503)
+            return max(0, (int(n) - (self.frame_size - self.frame_step)) // self.frame_step)
         return int(capi.check(capi.load().mfcc_frames_for_length(int(n), self.frame_size, self.frame_step)))
 
     def __del__(self):
@@ -261,7 +267,7 @@ class MFCC:
 
 def mfcc39(audio, lengths=None, fs=16000, frame_time=25, step_time=10, num_bins=26, low_freq=0, numcep=13,
            lift_factor=22, pad_fac=2, preemph=0.97, spectrum="power", window=None, floor_mel=False, out=None,
-           kind="mfcc39", num_fft=None):
+           kind="mfcc39", num_fft=None, frame_rule="pad", log_floor=0.0):
     """int16/float audio -> float32 [sum F, 39] = [c0=lnE, c1..c12 | delta | delta-delta]
     (the row layout of spectrograms(), mfcc-self5.py:181-186).  ``audio`` is one utterance
     [L], a dense batch [B, L], or a packed batch [sum L] with ``lengths``."""
@@ -269,7 +275,7 @@ def mfcc39(audio, lengths=None, fs=16000, frame_time=25, step_time=10, num_bins=
     fe.plan = get_plan(None if not isinstance(audio, torch.Tensor) or not audio.is_cuda else audio.device,
                        fs=fs, frame_time=frame_time, step_time=step_time, num_bins=num_bins, low_freq=low_freq,
                        numcep=numcep, lift_factor=lift_factor, pad_fac=pad_fac, preemph=preemph, spectrum=spectrum,
-                       window=window, floor_mel=floor_mel, num_fft=num_fft)
+                       window=window, floor_mel=floor_mel, num_fft=num_fft, frame_rule=frame_rule, log_floor=log_floor)
     fe._layouts = _layout_cache.setdefault(id(fe.plan), {})
     return fe(audio, lengths, out=out, kind=kind)
 

@@ -356,3 +356,23 @@ def pad_sequences(sequences, maxlen=None, padding="post", truncating="post", val
         else:
             x[i, -len(trunc):] = trunc
     return x, lengths
+
+
+def spec_anal(sig, bpre, framelength=400, frameshift=160, nfft=512, use_preemp=True):
+    """spec_anal of anal_recog_nn_liste.m:497-532 for fs > 8000: filter(bpre, 1, sig) with its
+    final state appended and the group delay dropped (:511-516), hamming(framelength) frames,
+    fix((L - noverlap)/frameshift) of them (:503), log(max(|fft|, 1)) (:529)."""
+    from scipy.signal import lfilter
+    sig = np.asarray(sig, dtype=np.float64)
+    if use_preemp:
+        b = np.asarray(bpre, dtype=np.float64)
+        y, z = lfilter(b, [1.0], sig, zi=np.zeros(len(b) - 1))
+        gd = (len(b) - 1) // 2
+        sig = np.concatenate([y[gd:], z[:gd]])
+    nframes = max(0, int((len(sig) - (framelength - frameshift)) / frameshift))
+    win = np.hamming(framelength)
+    spec = np.zeros((nframes, nfft // 2 + 1))
+    for t in range(nframes):
+        frame = win * sig[t * frameshift: t * frameshift + framelength]
+        spec[t] = np.log(np.maximum(np.abs(np.fft.fft(frame, nfft)[: nfft // 2 + 1]), 1.0))
+    return spec

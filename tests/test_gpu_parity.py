@@ -575,3 +575,34 @@ def test_8khz_geometry_with_512_point_fft(variant):
     # the reference's own winfft would take a 256-point FFT at this frame size: not built
     with pytest.raises(mfcc_amd.frontend.capi.MfccError):
         mfcc_amd.MFCC(variant, fs=8000)
+
+
+@pytest.mark.gpu
+def test_matlab_spec_anal_mode():
+    """spec_anal (anal_recog_nn_liste.m:497-532): parity with the reference itself is unpinned (no
+    Matlab); held to the numpy/scipy restatement of the cited lines."""
+    from mfcc_amd import matlab as M
+    rng = np.random.default_rng(17)
+    lengths = [5000, 399, 400, 240, 16000, 561]
+    audios = [np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths]
+    got = M.spec_anal(np.concatenate(audios), lengths=lengths)
+    pos = 0
+    for a in audios:
+        ref = O.spec_anal(a, M.initdft["bpre"])
+        n = ref.shape[0]
+        assert n == max(0, (len(a) - 240) // 160)
+        assert_logmel(got[pos:pos + n], ref, f"spec_anal L={len(a)}")
+        pos += n
+    assert pos == got.shape[0]
+    # the filter alone, including utterance boundaries, and without pre-emphasis
+    y = M.fir_centered(torch.from_numpy(np.concatenate(audios)).cuda(), lengths, M.initdft["bpre"], 7).cpu().numpy()
+    pos = 0
+    for a in audios:
+        full = np.convolve(a.astype(np.float64), np.asarray(M.initdft["bpre"]))[7:7 + len(a)]
+        np.testing.assert_allclose(y[pos:pos + len(a)], full, rtol=0, atol=2e-2)   # float32 sums of 15 terms ~1e4
+        pos += len(a)
+    ref = O.spec_anal(audios[0], M.initdft["bpre"], use_preemp=False)
+    assert_logmel(M.spec_anal(audios[0], init=dict(use_preemp=False)), ref, "spec_anal without pre-emphasis")
+    mm, vv = -ref.mean(0), 1.0 / ref.std(0)
+    normed = M.spec_anal(audios[0], init=dict(use_preemp=False), mm=mm, vv=vv)
+    np.testing.assert_allclose(normed, (ref + mm) * vv, rtol=0, atol=2e-3)
