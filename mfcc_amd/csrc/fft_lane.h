@@ -91,6 +91,17 @@ __device__ __forceinline__ cf cmulk(cf a, cf w) {
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
   return d;
 }
+// (a.x + b.y, a.x - b.y) and (a.y - b.x, a.y + b.x): the x parts, resp. y parts, of a - i b and a + i b
+__device__ __forceinline__ cf pair_x(cf a, cf b) {
+  cf d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ cf pair_y(cf a, cf b) {
+  cf d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 // |a|^2
 __device__ __forceinline__ float norm2(cf a) {
   const cf t = a * a;
@@ -104,6 +115,8 @@ MFCC_HD cf sub_conj(cf a, cf b) { return mk(a.x - b.x, a.y + b.y); }
 MFCC_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }
 MFCC_HD cf cmul(cf a, cf w) { return mk(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
 MFCC_HD cf cmulk(cf a, cf w) { return cmul(a, w); }
+MFCC_HD cf pair_x(cf a, cf b) { return mk(a.x + b.y, a.x - b.y); }
+MFCC_HD cf pair_y(cf a, cf b) { return mk(a.y - b.x, a.y + b.x); }
 MFCC_HD float norm2(cf a) { return a.x * a.x + a.y * a.y; }
 #endif
 
@@ -172,8 +185,16 @@ MFCC_HD void untangle_power(cf a, cf b, cf w, float& p_lo, float& p_hi) {
   const cf A = add_conj(a, b);
   const cf B = sub_conj(a, b);
   const cf C = cmul(B, w);
-  p_lo = norm2(add_mi(A, C));
-  p_hi = norm2(sub_mi(A, C));
+  // U = A - iC, V = A + iC held as X = (U.x, V.x), Y = (U.y, V.y): both squared moduli come out
+  // of one packed multiply and one packed fma
+  const cf X = pair_x(A, C), Y = pair_y(A, C);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const cf p = __builtin_elementwise_fma(Y, Y, X * X);
+#else
+  const cf p = mk(X.x * X.x + Y.x * Y.x, X.y * X.y + Y.y * Y.y);
+#endif
+  p_lo = p.x;
+  p_hi = p.y;
 }
 
 }  // namespace mfcc
