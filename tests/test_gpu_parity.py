@@ -606,3 +606,29 @@ def test_matlab_spec_anal_mode():
     mm, vv = -ref.mean(0), 1.0 / ref.std(0)
     normed = M.spec_anal(audios[0], init=dict(use_preemp=False), mm=mm, vv=vv)
     np.testing.assert_allclose(normed, (ref + mm) * vv, rtol=0, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,dtype", [("self5", np.int16), ("self15", np.int16), ("self5", np.float32)])
+def test_randomised_ragged_batch_around_tile_boundaries(variant, dtype):
+    """Seeded ragged batch whose frame counts straddle the fused kernel's tile size (300 output
+    frames, 4-frame halos) and the batch size (16), next to very short utterances."""
+    import mfcc_amd
+    rng = np.random.default_rng(1234)
+    frames = [1, 2, 4, 5, 15, 16, 17, 31, 32, 33] + list(range(290, 314, 3)) + [599, 600, 601, 607, 608, 609, 905]
+    lengths = [400 + 160 * (f - 1) - int(rng.integers(0, 160)) if f > 1 else int(rng.integers(1, 401)) for f in frames]
+    lengths += [int(v) for v in rng.integers(1, 3000, size=40)]
+    audios = []
+    for n in lengths:
+        a = rng.standard_normal(n) * 3000
+        audios.append(np.clip(a, -32768, 32767).astype(np.int16) if dtype == np.int16 else (a / 32768).astype(np.float32))
+    order = rng.permutation(len(lengths))
+    audios = [audios[i] for i in order]
+    lengths = [lengths[i] for i in order]
+    out = mfcc_amd.MFCC(variant)(np.concatenate(audios), lengths=lengths)
+    pos = 0
+    for a in audios:
+        ref = O.mfcc39(a, variant, loop=False)
+        assert_cep(out[pos:pos + ref.shape[0]], ref, f"L={len(a)}")
+        pos += ref.shape[0]
+    assert pos == out.shape[0]
