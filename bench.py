@@ -185,7 +185,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "mfcc::fused_kernel<0, 13, short>", "kernel_ms": round(kernel_ms, 4),
+                "kernel": "mfcc::fused_kernel<0, 13, short, mfcc::FrameGeom<400, 160>>", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "traffic_bytes_per_launch": traffic_bytes,
                 "traffic_source": "profiles/r1_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",

@@ -48,6 +48,25 @@ def timed(fn, steps, warmup=2):
     return ms[0], ms[len(ms) // 2]
 
 
+def config_b_variants(args):
+    """The headline shape through the other entry conditions: magnitude variant, float32 samples, static-only."""
+    n = 10000
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    audio = synth(n, gen)
+    faudio = (audio.float() / 32768).view(-1)
+    for variant, buf, kind in (("self5", audio.view(-1), "mfcc39"), ("self15", audio.view(-1), "mfcc39"),
+                               ("self5", faudio, "mfcc39"), ("self5", audio.view(-1), "static"),
+                               ("self5", audio.view(-1), "logmel")):
+        fe = mfcc_amd.MFCC(variant)
+        lay = fe.layout([UTT_LEN] * n)
+        out = torch.empty((lay.total_frames, fe.plan.out_width(kind)), dtype=torch.float32, device="cuda")
+        t = timed(lambda: fe.forward(buf, lay, out=out, kind=kind), 20, 3)
+        alg = buf.element_size() * buf.numel() + 4 * out.shape[1] * lay.total_frames
+        print(json.dumps({"config": f"B variant: {variant}, {str(buf.dtype).split('.')[-1]} samples, kind {kind}",
+                          "ms_min_med": [round(v, 4) for v in t], "frames_per_s": round(lay.total_frames / (t[1] * 1e-3), 1),
+                          "algorithmic_bytes": alg, "roofline_frac": round(alg / (t[1] * 1e-3) / 1e9 / HBM, 4)}), flush=True)
+
+
 def config_c(args):
     n = 10000
     gen = torch.Generator(device="cuda").manual_seed(1234)
@@ -177,10 +196,13 @@ def config_pcie(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="C,D,E,pcie")
+    ap.add_argument("--only", default="B,C,D,E,pcie")
     ap.add_argument("--utts-d", type=int, default=150000)
     args = ap.parse_args()
     which = set(args.only.split(","))
+    if "B" in which:
+        config_b_variants(args)
+        torch.cuda.empty_cache()
     if "C" in which:
         config_c(args)
         torch.cuda.empty_cache()
