@@ -632,3 +632,34 @@ def test_randomised_ragged_batch_around_tile_boundaries(variant, dtype):
         assert_cep(out[pos:pos + ref.shape[0]], ref, f"L={len(a)}")
         pos += ref.shape[0]
     assert pos == out.shape[0]
+
+
+@pytest.mark.gpu
+def test_forward_is_graph_capturable():
+    """mfcc_forward only enqueues one kernel on the caller's stream (no allocation, no host
+    synchronisation), so a launch-bound caller can capture it in a HIP graph and replay it."""
+    import mfcc_amd
+    rng = np.random.default_rng(4)
+    lengths = [3000, 16000, 777]
+    audio = torch.from_numpy(np.clip(rng.standard_normal(sum(lengths)) * 3000, -32768, 32767).astype(np.int16)).cuda()
+    fe = mfcc_amd.MFCC("self5")
+    lay = fe.layout(lengths)
+    out = torch.zeros((lay.total_frames, 39), dtype=torch.float32, device="cuda")
+    eager = fe.forward(audio, lay).clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fe.forward(audio, lay, out=out)          # warm-up on the side stream
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fe.forward(audio, lay, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    audio2 = torch.from_numpy(np.clip(rng.standard_normal(sum(lengths)) * 3000, -32768, 32767).astype(np.int16)).cuda()
+    audio.copy_(audio2)                          # new samples in the captured buffer, same launch
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, fe.forward(audio2, lay))
