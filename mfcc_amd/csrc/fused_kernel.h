@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const dctb = hbuf + kHbufFloats;
   float* const twl = dctb + kDctBFloats;
 
+  constexpr bool kSpecOut = (OUT == kOutSpec || OUT == kOutLogspec);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -434,6 +435,15 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         for (int s = 0; s < kMelSteps; ++s) bv[s] = melB[s * 64];
       }
       float* const P = xbuf + fb * kSlot;
+      // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
+      float* const spec_row = (kSpecOut && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
+      const float spec_scale = kSpecOut ? pc->spec_scale : 0.f, spec_floor = kSpecOut ? pc->log_floor : 0.f;
+      auto spec_value = [&](float p4) {
+        // LDS rows would hold 4|X|^2 (power) or, after the square root, 2|X| (magnitude)
+        float v = (mag ? __builtin_amdgcn_sqrtf(p4) : p4) * spec_scale;
+        if (OUT == kOutLogspec) v = fast_ln(fmaxf(v, spec_floor));  // floor 0 = none: ln 0 = -inf as np.log
+        return v;
+      };
       // Z[256-k] lives in the partner lane: fetch four partners and four untangle twiddles at
       // a time, so that their latencies overlap instead of adding up
 #pragma unroll
@@ -452,15 +462,28 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #else
           lo = x[h + s].x + pb[s].x + pw[s].x; hi = x[h + s].y + pb[s].y + pw[s].y;
 #endif
-          P[q + 16 * (h + s)] = lo;
-          P[256 - q - 16 * (h + s)] = hi;
+          if (kSpecOut) {
+            // spectrum kinds: scale (sqrt, ln) and write the two bins of this lane straight from
+            // registers to the output row of the frame; no trip through LDS, no barrier
+            if (spec_row) {
+              spec_row[q + 16 * (h + s)] = spec_value(lo);
+              spec_row[256 - q - 16 * (h + s)] = spec_value(hi);
+            }
+          } else {
+            P[q + 16 * (h + s)] = lo;
+            P[256 - q - 16 * (h + s)] = hi;
+          }
         }
       }
       if (q == 0) {  // bin 128 pairs with itself: X[128] = conj Z[128]
-        P[128] = 4.f * norm2(x[8]);
-        P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-steps
+        if (kSpecOut) {
+          if (spec_row) spec_row[128] = spec_value(4.f * norm2(x[8]));
+        } else {
+          P[128] = 4.f * norm2(x[8]);
+          P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-steps
+        }
       }
-      if (mag) {
+      if (mag && !kSpecOut) {
         // magnitude spectrum (mfcc-self15.py:234): a pass of its own over the row, so that the
         // power path does not pay for the square roots
         wave_sync();
@@ -478,16 +501,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     MFCC_STAMP(tb2);
     const bool more = tb + kBatch < s_hi;
 
-    if (OUT == kOutSpec || OUT == kOutLogspec) {
-      const int nvalid = min(kBatch, s_hi - tb);
-      const float scale = pc->spec_scale, lfloor = pc->log_floor;
+    if (kSpecOut) {
+      // rows are already written; the barrier above only released the staged audio
       stage_ld(tb + kBatch);
-      for (int idx = tid; idx < nvalid * kNbin; idx += 256) {
-        const int f = idx / kNbin, k = idx - f * kNbin;
-        float v = xbuf[f * kSlot + k] * scale;
-        if (OUT == kOutLogspec) v = fast_ln(fmaxf(v, lfloor));  // floor 0 = none: ln 0 = -inf as np.log
-        out_t0[(tb - t0 + f) * ld + k] = v;
-      }
       if (more) delta = stage_st(tb + kBatch);
       __syncthreads();
       continue;
