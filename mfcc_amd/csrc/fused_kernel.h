@@ -61,7 +61,13 @@ constexpr int kMelSteps = 24;     // MFMA k-steps (4 bins each) every wave runs
 constexpr int kDctSteps = (kMaxMel + 3) / 4;
 
 // LDS carve (floats).
-constexpr int kSlot = 514;                           // spectrum row of frame f starts at f*514
+constexpr int kSlot = 514;                           // LDS floats per frame slot (exchange buffer 512 + skew room)
+// Spectrum row of frame slot r starts at r*512 + row_skew(r) floats.  The skew is a bank offset
+// that serves both access patterns of the rows without conflicts: the untangle writes 16
+// consecutive columns from each of a wave's 4 frames (offsets 0,16,8,24 of rows 4w..4w+3 tile the
+// 32 banks exactly twice), the filterbank reads 4 consecutive columns of all 16 rows (16 distinct
+// even offsets).
+__host__ __device__ constexpr int row_skew(int r) { return 2 * (r >> 2) + 8 * ((r >> 1) & 1) + 16 * (r & 1); }
 constexpr int kRowPad = 260;                         // bins 0..256 plus zeros up to a multiple of 4
 constexpr int kXbufFloats = kBatch * kSlot;          // exchange buffers (fb*512) / spectrum rows; epilogue scratch
 constexpr int kAbufFloats = 2808;                    // staged audio: kStage + up to 7 alignment samples, whole chunks
@@ -434,7 +440,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
         for (int s = 0; s < kMelSteps; ++s) bv[s] = melB[s * 64];
       }
-      float* const P = xbuf + fb * kSlot;
+      float* const P = xbuf + fb * 512 + row_skew(fb);
       // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
       float* const spec_row = (kSpecOut && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
       const float spec_scale = kSpecOut ? pc->spec_scale : 0.f, spec_floor = kSpecOut ? pc->log_floor : 0.f;
@@ -516,7 +522,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #endif
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-      const float* Prow = xbuf + q * kSlot + g4 + mel_k0;
+      const float* Prow = xbuf + q * 512 + row_skew(q) + g4 + mel_k0;
 #ifndef MFCC_ABL_MEL
       // All kMelSteps k-steps run unconditionally (no branch between them, so the operand reads
       // are issued ahead of the chain); steps a wave does not need carry zero weights, and the
