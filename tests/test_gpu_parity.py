@@ -663,3 +663,16 @@ def test_forward_is_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, fe.forward(audio2, lay))
+
+
+@pytest.mark.gpu
+def test_streaming_large_chunks_span_several_tiles():
+    """A push that brings more frames than one tile of the fused kernel holds (here 625 and 312)."""
+    import mfcc_amd
+    rng = np.random.default_rng(8)
+    audio = np.clip(rng.standard_normal((2, 150000)) * 3000, -32768, 32767).astype(np.int16)
+    s = mfcc_amd.StreamingMFCC("self5", n_streams=2, max_chunk=100000)
+    got = _stream_all(s, torch.from_numpy(audio).cuda(), [100000, 50000]).cpu().numpy()
+    off = mfcc_amd.MFCC("self5")(torch.from_numpy(audio).cuda()).cpu().numpy().reshape(2, -1, 39)
+    assert got.shape == off.shape
+    np.testing.assert_allclose(got, off, rtol=0, atol=2e-5)
