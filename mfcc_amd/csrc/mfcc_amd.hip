@@ -67,7 +67,6 @@ struct mfcc_layout {
   int64_t* d_sample_off = nullptr;
   int64_t* d_frame_off = nullptr;
   mfcc::Tile* d_tiles = nullptr;
-  int32_t* d_row_utt = nullptr;
   int64_t n_tiles;
 };
 
@@ -404,15 +403,11 @@ int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64
     delete l;
     return fail(MFCC_ERR_UNSUPPORTED, "layout needs more than 2^31-1 workgroups; split the batch");
   }
-  std::vector<int32_t> row_utt((size_t)l->total_frames);
-  for (int64_t u = 0; u < n_utts; ++u)
-    for (int64_t r = l->frame_off[u]; r < l->frame_off[u + 1]; ++r) row_utt[(size_t)r] = (int32_t)u;
   hipError_t e = hipSetDevice(plan->device);
   int rc = e == hipSuccess ? MFCC_OK : fail(MFCC_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
   if (!rc) rc = upload(l->sample_off, &l->d_sample_off);
   if (!rc) rc = upload(l->frame_off, &l->d_frame_off);
   if (!rc) rc = upload(tiles, &l->d_tiles);
-  if (!rc) rc = upload(row_utt, &l->d_row_utt);
   if (rc) {
     mfcc_layout_destroy(l);
     return rc;
@@ -426,7 +421,6 @@ int mfcc_layout_destroy(mfcc_layout* l) {
   (void)hipFree(l->d_sample_off);
   (void)hipFree(l->d_frame_off);
   (void)hipFree(l->d_tiles);
-  (void)hipFree(l->d_row_utt);
   delete l;
   return MFCC_OK;
 }
@@ -590,10 +584,10 @@ int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t fe
   if (((uintptr_t)out & 15) == 0 && (int64_t)framenum * ncol * mfcc::kStackRows < (1 << 24)) {
     const int64_t nblk = ((layout->total_frames + mfcc::kStackRows - 1) / mfcc::kStackRows + 7) / 8 * 8;  // whole rounds over the 8 XCDs
     hipLaunchKernelGGL(mfcc::stack_context_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, feats, feats_ld, ncol,
-                       framenum, layout->d_frame_off, layout->d_row_utt, out, layout->total_frames);
+                       framenum, layout->d_frame_off, (int)layout->n_utts, out, layout->total_frames);
   } else {
     hipLaunchKernelGGL(mfcc::stack_context_kernel, dim3((unsigned)layout->total_frames), dim3(256), 0, (hipStream_t)stream, feats, feats_ld,
-                       ncol, framenum, layout->d_frame_off, layout->d_row_utt, out);
+                       ncol, framenum, layout->d_frame_off, (int)layout->n_utts, out);
   }
   HIP_TRY(hipGetLastError());
   return MFCC_OK;

@@ -141,6 +141,17 @@ __global__ void __launch_bounds__(256) fir_kernel(const T* __restrict__ x, const
   }
 }
 
+// Utterance that owns output row `row`: the last u with frame_off[u] <= row (utterances without
+// frames share their offset with the next one and are skipped by taking the last).
+__device__ __forceinline__ int utt_of_row(const int64_t* __restrict__ frame_off, int n_utts, int64_t row) {
+  int lo = 0, hi = n_utts - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (frame_off[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // Context stacking, MLP_5hidlayer_40.py:70-105: one workgroup per output row t of
 // utterance u; out[t, f*C + c] = feats[clamp(t + f - h), c].  The write of N*C contiguous
 // floats per row is the traffic that matters (N x the read, which stays in L2): the row is
@@ -148,9 +159,9 @@ __global__ void __launch_bounds__(256) fir_kernel(const T* __restrict__ x, const
 // 16-byte alignment first), the source values are gathered with 4-byte loads.
 __global__ void __launch_bounds__(256) stack_context_kernel(const float* __restrict__ feats, int64_t feats_ld, int ncol,
                                                             int framenum, const int64_t* __restrict__ frame_off,
-                                                            const int32_t* __restrict__ row_utt, float* __restrict__ out) {
+                                                            int n_utts, float* __restrict__ out) {
   const int64_t row = blockIdx.x;
-  const int u = row_utt[row];
+  const int u = utt_of_row(frame_off, n_utts, row);  // every thread walks the same 17 or so steps (L1/L2-resident)
   const int64_t f0 = frame_off[u], f1 = frame_off[u + 1];
   const int half = (framenum - 1) / 2;
   const int width = framenum * ncol;
@@ -207,7 +218,7 @@ __global__ void __launch_bounds__(256) stack_context_kernel(const float* __restr
 constexpr int kStackRows = 8;
 __global__ void __launch_bounds__(256) stack_context_rows_kernel(const float* __restrict__ feats, int64_t feats_ld, int ncol,
                                                                  int framenum, const int64_t* __restrict__ frame_off,
-                                                                 const int32_t* __restrict__ row_utt, float* __restrict__ out,
+                                                                 int n_utts, float* __restrict__ out,
                                                                  int64_t total_rows) {
   __shared__ int64_t lo[kStackRows], hi[kStackRows];
   // Workgroups are handed to the 8 XCDs round-robin and each XCD has its own L2: give every XCD
@@ -220,7 +231,7 @@ __global__ void __launch_bounds__(256) stack_context_rows_kernel(const float* __
   const int64_t row0 = blk * kStackRows;
   const int nrows = (int)(total_rows - row0 < kStackRows ? total_rows - row0 : kStackRows);
   if ((int)threadIdx.x < nrows) {
-    const int u = row_utt[row0 + threadIdx.x];
+    const int u = utt_of_row(frame_off, n_utts, row0 + threadIdx.x);
     lo[threadIdx.x] = frame_off[u];
     hi[threadIdx.x] = frame_off[u + 1] - 1;
   }
