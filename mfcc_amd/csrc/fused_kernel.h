@@ -112,8 +112,8 @@ struct MelMap {
 // that they do not occupy scalar registers across the batch loop.
 struct PlanConst {
   const float* tw512;     // [512][2]  exp(-2 pi i m / 512)
-  const float* melB;      // [4][kMelSteps][64] B operands (filter weights * spec_scale) in lane order
-  const float* dctB;      // [kDctSteps][64] B operands of the DCT*lifter product in lane order
+  const float* melB;      // [4][kMelSteps/4][64][4] B operands (filter weights * spec_scale): 16 B per lane and 4 k-steps
+  const float* dctB;      // [kDctSteps/2][64][2] B operands of the DCT*lifter product: 8 B per lane and 2 k-steps
   const float* window;    // [512] or nullptr
   MelMap map;
   int32_t mel_steps[4];   // k-steps wave w really needs (<= kMelSteps)
@@ -319,7 +319,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const gfloat_ptr window = as_global(pc->window);
   // this wave's share of the filterbank product
   const int mel_k0 = pc->map.kstart[wave], mel_nf = pc->map.nfilt[wave], mel_ff = pc->map.first_filter[wave];
-  const gfloat_ptr melB = as_global(pc->melB) + (wave * kMelSteps) * 64 + lane;
+  typedef const f32x4 __attribute__((address_space(1))) * gfloat4_ptr;
+  const gfloat4_ptr melB4 = (gfloat4_ptr)(uintptr_t)pc->melB + (wave * (kMelSteps / 4)) * 64 + lane;
+  static_assert(kMelSteps % 4 == 0, "filterbank operands are fetched four k-steps at a time");
 
   // Twiddles per lane index q: stage 1 uses W256^(q k1) = W512^(2 q k1), k1 = 1..15, the
   // untangle W512^(q + 16 s), s = 0..7.  They live in LDS (row q, 23 complex values) and are
@@ -438,7 +440,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       if (OUT != kOutSpec && OUT != kOutLogspec) {
         // fetch the filterbank operands of this wave now (L2 latency ~ the untangle below)
 #pragma unroll
-        for (int s = 0; s < kMelSteps; ++s) bv[s] = melB[s * 64];
+        for (int s = 0; s < kMelSteps; s += 4) {
+          const f32x4 w4 = melB4[(s / 4) * 64];
+          bv[s] = w4.x; bv[s + 1] = w4.y; bv[s + 2] = w4.z; bv[s + 3] = w4.w;
+        }
       }
       float* const P = xbuf + fb * 512 + row_skew(fb);
       // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
@@ -597,7 +602,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
       for (int s = 0; s < kDctSteps; ++s) {
         la[s] = Lr[4 * s];
-        lb[s] = dctb[s * 64 + lane];
+        lb[s] = dctb[((s >> 1) * 64 + lane) * 2 + (s & 1)];  // pairs of k-steps are one 8-byte read
       }
 #pragma unroll
       for (int s = 0; s < kDctSteps; s += 2) {

@@ -281,7 +281,8 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
           if (j < pmap.nfilt[g]) w = bank[(size_t)(best_cut[g] + j) * mfcc::kNbin + k];
           else if (j == mfcc::kMelCols && k >= best_es[g] && k < best_es[g + 1]) w = 1.0;
         }
-        melB[((size_t)g * mfcc::kMelSteps + sidx) * 64 + lane] = (float)(w * (double)p->spec_scale);
+        // four consecutive k-steps of a lane are 16 contiguous bytes: [wave][step/4][lane][step%4]
+        melB[(((size_t)g * (mfcc::kMelSteps / 4) + sidx / 4) * 64 + lane) * 4 + sidx % 4] = (float)(w * (double)p->spec_scale);
       }
   }
   pmap.ndct = (nmel + 3) / 4;
@@ -290,7 +291,8 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   for (int sidx = 0; sidx < pmap.ndct; ++sidx)
     for (int lane = 0; lane < 64; ++lane) {
       const int m = 4 * sidx + (lane >> 4), c = lane & 15;
-      if (m < nmel && c < cfg->numcep) dctB[(size_t)sidx * 64 + lane] = (float)dl[(size_t)m * cfg->numcep + c];
+      if (m < nmel && c < cfg->numcep)  // [step/2][lane][step%2]: two k-steps of a lane are 8 contiguous bytes
+        dctB[((size_t)(sidx / 2) * 64 + lane) * 2 + sidx % 2] = (float)dl[(size_t)m * cfg->numcep + c];
     }
   std::vector<float> win;
   if (cfg->window == MFCC_WINDOW_HAMMING) {
