@@ -194,32 +194,53 @@ struct StageRegs {
 // zeros by stage_store.  Being branch-free matters: the loads stay in one basic block with the
 // matrix-core section that follows, which lets the compiler wait for the filterbank operands
 // without also waiting for these (younger, HBM-latency) loads.
+// Per-tile constants of the staging loads.  All batches of a tile share the alignment offset
+// delta (16 frames advance by a multiple of 16 bytes), so the clamps are 32-bit element offsets
+// from the tile's first aligned chunk, set up once; a batch only adds its own offset.
+template <typename T>
+struct StageCtx {
+  const T* base;   // aligned chunk 0 of the tile's first batch
+  int hi_rel;      // offset of the last aligned chunk that still holds a byte of the buffer (>= 0)
+  int last_rel;    // offset of the last element of the buffer
+  int front_rel;   // offset of the first element of the buffer (<= 0 except by misalignment)
+  int delta;
+  unsigned nchunk;
+};
+
 template <typename T, class G>
-__device__ __forceinline__ void stage_load(const T* buf, int64_t total, int64_t s_off, StageRegs& r, int tb, int tid) {
-  // buf/total = the whole audio buffer (total >= 1), s_off = first sample of the utterance
-  constexpr int CE = 16 / (int)sizeof(T);  // elements per chunk
-  constexpr int NR = sizeof(T) == 2 ? 2 : 3;
-  constexpr int64_t kBig = 1 << 24;
-  const T* const b0 = buf + s_off + (int64_t)tb * G::kStep;  // first sample of the batch
-  const int delta = (int)(((uintptr_t)b0 & 15) / sizeof(T));
-  const T* const a0 = b0 - delta;                               // aligned chunk 0
-  const T* const last = buf + (total - 1);                      // last element of the buffer
+__device__ __forceinline__ StageCtx<T> stage_setup(const T* buf, int64_t total, int64_t s_off, int t_first) {
+  // buf/total = the whole audio buffer (total >= 1), s_off = first sample of the utterance,
+  // t_first = first frame the tile computes (its first sample lies inside the buffer)
+  constexpr int CE = 16 / (int)sizeof(T);
+  constexpr int64_t kBig = 1 << 28;
+  static_assert((16 * G::kStep * sizeof(T)) % 16 == 0, "batches must keep the 16-byte phase");
+  const T* const b0 = buf + s_off + (int64_t)t_first * G::kStep;
+  StageCtx<T> c;
+  c.delta = (int)(((uintptr_t)b0 & 15) / sizeof(T));
+  c.base = b0 - c.delta;
+  const T* const last = buf + (total - 1);
   const T* const hi_chunk = last - (((uintptr_t)last & 15) / sizeof(T));
-  const T* const a0c = a0 < hi_chunk ? a0 : hi_chunk;
-  const T* const p0 = a0c - 1;                                  // element in front of chunk 0 (offset-only use)
-  const int64_t hi64 = hi_chunk - a0c, hip64 = last - p0;
-  const unsigned hi_el = (unsigned)(hi64 < kBig ? hi64 : kBig), hip_el = (unsigned)(hip64 < kBig ? hip64 : kBig);
-  const unsigned lop_el = a0c > buf ? 0u : (unsigned)(buf - a0c) + 1u;  // first offset from p0 inside the buffer
-  const unsigned nchunk = (delta + G::kStageLen + CE - 1) / CE;
-  r.delta = delta;
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const unsigned c = min((unsigned)(tid + 256 * k), nchunk - 1);
-    r.raw[k] = *(const uint4*)(a0c + min(c * CE, hi_el));
-    r.prev[k] = (float)p0[min(max(c * CE, lop_el), hip_el)];
-  }
+  const int64_t hi64 = hi_chunk - c.base, last64 = last - c.base, front64 = buf - c.base;
+  c.hi_rel = (int)(hi64 < kBig ? hi64 : kBig);
+  c.last_rel = (int)(last64 < kBig ? last64 : kBig);
+  c.front_rel = (int)(front64 > -kBig ? front64 : -kBig);
+  c.nchunk = (c.delta + G::kStageLen + CE - 1) / CE;
+  return c;
 }
 
+template <typename T, class G>
+__device__ __forceinline__ void stage_load(const StageCtx<T>& c, StageRegs& r, int batch_off, int tid) {
+  // batch_off = (first frame of the batch - first frame of the tile) * step, in elements
+  constexpr int CE = 16 / (int)sizeof(T);  // elements per chunk
+  constexpr int NR = sizeof(T) == 2 ? 2 : 3;
+  r.delta = c.delta;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int e = batch_off + (int)min((unsigned)(tid + 256 * k), c.nchunk - 1) * CE;
+    r.raw[k] = *(const uint4*)(c.base + min(e, c.hi_rel));
+    r.prev[k] = (float)c.base[min(max(e - 1, c.front_rel), c.last_rel)];
+  }
+}
 template <typename T, class G>
 __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int64_t len, int tb, int tid,
                                             float pre_hi, float pre_lo) {
@@ -338,7 +359,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const int partner_addr = ((lane & 48) | partner_lane(q)) << 2;
 
   StageRegs sr;
-  auto stage_ld = [&](int tb) { stage_load<T, G>((const T*)p.audio, p.total_elems, s_off, sr, tb, tid); };
+  const StageCtx<T> sctx = stage_setup<T, G>((const T*)p.audio, p.total_elems, s_off, s_lo);
+  auto stage_ld = [&](int tb) { stage_load<T, G>(sctx, sr, (tb - s_lo) * G::kStep, tid); };
   auto stage_st = [&](int tb) -> int {
     stage_store<T, G>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
     return sr.delta;
