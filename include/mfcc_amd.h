@@ -87,6 +87,7 @@ typedef struct mfcc_stream mfcc_stream; /* state of a batch of live audio stream
 int mfcc_version(void);
 const char* mfcc_last_error(void);
 void mfcc_config_default(mfcc_config* cfg); /* = mfcc-self5.py main(), :211-229 */
+int32_t mfcc_config_size(void);             /* sizeof(mfcc_config) of this build: lets a binding check its struct */
 
 /* ---- host-side constants (double precision, no device needed) -------------- */
 /* melbanks(fs, numbins, lowfreq, num_fft) -> [numbins, num_fft/2+1] row-major.  mfcc-self5.py:102-117 */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mfcc_version": (C.c_int, []),
     "mfcc_last_error": (C.c_char_p, []),
     "mfcc_config_default": (None, [C.POINTER(MfccConfig)]),
+    "mfcc_config_size": (_i32, []),
     "mfcc_melbank_host": (C.c_int, [_dbl, _i32, _dbl, _i32, _dblp]),
     "mfcc_frame_geometry": (C.c_int, [_dbl, _dbl, _dbl, _i32p, _i32p, _i32p]),
     "mfcc_frames_for_length": (_i64, [_i64, _i32, _i32]),
@@ -106,6 +107,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.mfcc_config_size() != C.sizeof(MfccConfig):
+        raise ImportError(f"{LIB_PATH}: struct mfcc_config has {lib.mfcc_config_size()} bytes, this binding expects "
+                          f"{C.sizeof(MfccConfig)}: rebuild the library (make)")
     _lib = lib
     return lib
 

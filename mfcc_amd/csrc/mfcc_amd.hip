@@ -138,6 +138,8 @@ int mfcc_version(void) { return 100; }
 
 const char* mfcc_last_error(void) { return g_err; }
 
+int32_t mfcc_config_size(void) { return (int32_t)sizeof(mfcc_config); }
+
 void mfcc_config_default(mfcc_config* cfg) {
   if (!cfg) return;
   cfg->fs = 16000;

@@ -122,3 +122,16 @@ def test_dataset_helpers_follow_the_reference(golden):
     x = np.arange(2 * 39, dtype=np.float32).reshape(2, 39)
     y = D.energy_last(x)
     assert np.array_equal(y[0, :13], np.r_[1:13, 0]) and np.array_equal(y[0, 13:26], np.r_[14:26, 13])
+
+
+def test_config_struct_matches_the_binding():
+    """The ctypes mirror of struct mfcc_config must have the library's size and defaults."""
+    import ctypes as C
+    from mfcc_amd import _capi as capi
+    lib = capi.load()
+    assert lib.mfcc_config_size() == C.sizeof(capi.MfccConfig)
+    cfg = capi.MfccConfig()
+    lib.mfcc_config_default(C.byref(cfg))
+    assert (cfg.fs, cfg.frame_time, cfg.step_time, cfg.num_bins, cfg.numcep, cfg.lift_factor, cfg.pad_fac) == (16000, 25, 10, 26, 13, 22, 2)
+    assert (cfg.use_preemph, cfg.preemph, cfg.spectrum, cfg.window, cfg.floor_mel, cfg.num_fft, cfg.frame_rule, cfg.log_floor) == \
+        (1, 0.97, capi.SPECTRUM_POWER, capi.WINDOW_NONE, 0, 0, 0, 0.0)
