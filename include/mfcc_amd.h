@@ -15,7 +15,8 @@
  *     device work is enqueued on it and the call returns without waiting;
  *   - a plan / layout belongs to the device it was created on; the caller
  *     keeps that device current while using it;
- *   - no call allocates device memory except the *_create functions.
+ *   - no call allocates device memory except the *_create functions and the first
+ *     mfcc_cmvn_accumulate on a (device, stream) pair.
  */
 #ifndef MFCC_AMD_H
 #define MFCC_AMD_H
@@ -113,6 +114,11 @@ int mfcc_plan_info(const mfcc_plan* plan, int32_t* frame_size, int32_t* frame_st
 int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64_t n_utts, mfcc_layout** out);
 int mfcc_layout_destroy(mfcc_layout* layout);
 int mfcc_layout_info(const mfcc_layout* layout, int64_t* n_utts, int64_t* total_samples, int64_t* total_frames);
+/* The same container for feature rows that did not come from audio through this library
+ * (.pat files, MLP_5hidlayer_40.py:61-68): utterance u owns frame_counts[u] >= 0 consecutive rows.
+ * Accepted by the row-wise entry points (stacking, padding, per-utterance normalisation), not by
+ * mfcc_forward / mfcc_fir. */
+int mfcc_layout_create_frames(int device, const int64_t* frame_counts_host, int64_t n_utts, mfcc_layout** out);
 /* copies the (n_utts+1) prefix sums to host arrays; either pointer may be NULL */
 int mfcc_layout_offsets_host(const mfcc_layout* layout, int64_t* sample_offsets_host, int64_t* frame_offsets_host);
 
@@ -150,17 +156,29 @@ int mfcc_fir(const mfcc_layout* layout, const void* audio, int32_t audio_dtype, 
              int32_t delay, float* out, void* stream);
 
 /* ---- context stacking ----------------------------------------------------------
- * padUtterance + slidingWin, MLP_5hidlayer_40.py:70-105:
- * out[t, f*C + c] = feats[clamp(t + f - (N-1)/2, 0, F_u-1), c] per utterance of the
- * layout (frame-major; N = framenum).  feats is [total_frames, C] with row stride feats_ld. */
+ * padUtterance + slidingWin per utterance of the layout; N = framenum (odd), h = (N-1)/2,
+ * feats is [total_frames, C] with row stride feats_ld.  Output row i holds the window of row
+ * t = row_index ? row_index[i] : i (row_index: device int64[n_out], rows of the packed array;
+ * NULL = all rows in order, n_out ignored) in one of two element orders:
+ *   MFCC_STACK_FRAME_MAJOR  out[i, f*C + c] = feats[clamp(t + f - h), c]   the MLP vector
+ *                           (reshape(..., order='F') of the [C,N] slice, MLP_5hidlayer_40.py:70-105)
+ *   MFCC_STACK_TILE         out[i, c*N + f] = feats[clamp(t + f - h), c]   the [C,N] slice itself, as the
+ *                           CNN scripts keep it (CNN_DenseNet40_6.py:98,124-131)
+ * row_index carries the shuffled window order of CNN_DenseNet40_6.py:91-97 (createRandomvec). */
+#define MFCC_STACK_FRAME_MAJOR 0
+#define MFCC_STACK_TILE 1
 int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t feats_ld, int32_t ncol,
-                       int32_t framenum, float* out, void* stream);
+                       int32_t framenum, int32_t out_layout, const int64_t* row_index, int64_t n_out, float* out,
+                       void* stream);
 
 /* ---- CMVN ---------------------------------------------------------------------------
  * sums[0] += n_rows, sums[1..D] += sum_x, sums[1+D..2D] += sum_x^2 (float64, device).
  * Generalises the per-utterance (x-mean)/std of inference_ctc_eri_05.py:291 and the
  * corpus constants (x+mm).*vv of anal_recog_nn_liste.m:180.  The caller zeroes `sums`
- * and all-reduces it across ranks. */
+ * and combines it across ranks.  The reduction order is fixed by the code (per-workgroup
+ * partial sums, then a fixed-order second stage; no atomics), so equal inputs give equal bits.
+ * The partial sums live in a buffer the library allocates on first use per (device, stream)
+ * and keeps; ncol <= 1024. */
 int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums,
                          void* stream);
 /* feats[r,c] = (feats[r,c] + mm[c]) * vv[c] in place; mm, vv are float32[ncol] on the device */

@@ -17,5 +17,5 @@ __all__ = [
     "spectrograms", "loadPatData", "writePatData", "padUtterance", "slidingWin",
     "frame_time", "step_time", "num_bins", "low_freq", "num_fft", "lift_factor", "delta_factor", "fs", "duration",
 ]
-from . import datasets, psf, sequences  # noqa: E402,F401  (counterparts of the reference's data plumbing / call sites)
+from . import cnn, datasets, psf, sequences  # noqa: E402,F401  (counterparts of the reference's data plumbing / call sites)
 from .sequences import ctc_feature_batch, pad_sequences, utterance_scalar_norm  # noqa: E402,F401

@@ -18,6 +18,7 @@ AUDIO_I16, AUDIO_F32 = 0, 1
 SPECTRUM_POWER, SPECTRUM_MAG = 0, 1
 WINDOW_NONE, WINDOW_HAMMING = 0, 1
 OUT_MFCC39, OUT_STATIC, OUT_LOGMEL, OUT_SPEC, OUT_LOGSPEC = 0, 1, 2, 3, 4
+STACK_FRAME_MAJOR, STACK_TILE = 0, 1
 
 
 class MfccConfig(C.Structure):
@@ -63,6 +64,7 @@ SIGNATURES = {
     "mfcc_plan_destroy": (C.c_int, [_vp]),
     "mfcc_plan_info": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "mfcc_layout_create": (C.c_int, [_vp, _i64p, _i64, C.POINTER(_vp)]),
+    "mfcc_layout_create_frames": (C.c_int, [C.c_int, _i64p, _i64, C.POINTER(_vp)]),
     "mfcc_layout_destroy": (C.c_int, [_vp]),
     "mfcc_layout_info": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
     "mfcc_layout_offsets_host": (C.c_int, [_vp, _i64p, _i64p]),
@@ -75,7 +77,7 @@ SIGNATURES = {
     "mfcc_delta": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "mfcc_fir": (C.c_int, [_vp, _vp, _i32, C.POINTER(C.c_float), _i32, _i32, _vp, _vp]),
     "mfcc_copy_cols": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
-    "mfcc_stack_context": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "mfcc_stack_context": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mfcc_cmvn_accumulate": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "mfcc_cmvn_apply": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "mfcc_utt_scalar_norm": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -45,6 +46,63 @@ int upload(const std::vector<T>& host, T** dev) {
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+// Partial sums of mfcc_cmvn_accumulate: one buffer per (device, stream) that has called it, grown
+// on demand and kept until the process ends.  Calls on one stream are ordered by the stream, calls
+// on different streams get different buffers.
+struct CmvnWorkspace {
+  int device;
+  hipStream_t stream;
+  double* ptr;
+  size_t bytes;
+};
+std::mutex g_ws_mutex;
+std::vector<CmvnWorkspace> g_ws;
+
+int cmvn_workspace(hipStream_t stream, size_t bytes, double** out) {
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  for (CmvnWorkspace& w : g_ws)
+    if (w.device == device && w.stream == stream) {
+      if (w.bytes < bytes) {
+        // the old buffer may still be read by work enqueued earlier on this stream
+        HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(w.ptr);
+        w.ptr = nullptr;
+        w.bytes = 0;
+        HIP_TRY(hipMalloc((void**)&w.ptr, bytes));
+        w.bytes = bytes;
+      }
+      *out = w.ptr;
+      return MFCC_OK;
+    }
+  double* p = nullptr;
+  HIP_TRY(hipMalloc((void**)&p, bytes));
+  g_ws.push_back(CmvnWorkspace{device, stream, p, bytes});
+  *out = p;
+  return MFCC_OK;
+}
+
+// Both stages of the CMVN reduction on `st`, partial sums in `partial` (>= nblk*2*ncol doubles).
+int launch_cmvn(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums, double* partial, int nblk,
+                int64_t rows_per_block, hipStream_t st) {
+  int threads = 256;
+  while (threads < ncol) threads += 64;
+  hipLaunchKernelGGL(mfcc::cmvn_partial_kernel, dim3((unsigned)nblk), dim3(threads), 2 * threads * sizeof(double), st, feats, feats_ld,
+                     n_rows, ncol, rows_per_block, partial);
+  hipLaunchKernelGGL(mfcc::cmvn_finish_kernel, dim3(2 * (unsigned)ncol), dim3(256), 0, st, partial, nblk, ncol, n_rows, sums);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+// Rows per stage-1 workgroup: 512 while that needs at most kCmvnMaxBlocks workgroups, more beyond.
+void cmvn_split(int64_t n_rows, int* nblk, int64_t* rows_per_block) {
+  int64_t rpb = 512;
+  if ((n_rows + rpb - 1) / rpb > mfcc::kCmvnMaxBlocks) rpb = (n_rows + mfcc::kCmvnMaxBlocks - 1) / mfcc::kCmvnMaxBlocks;
+  *rows_per_block = rpb;
+  *nblk = (int)((n_rows + rpb - 1) / rpb);
+}
+
 }  // namespace
 
 struct mfcc_plan {
@@ -68,6 +126,7 @@ struct mfcc_layout {
   int64_t* d_frame_off = nullptr;
   mfcc::Tile* d_tiles = nullptr;
   int64_t n_tiles;
+  bool frames_only = false;  // made by mfcc_layout_create_frames: frame offsets only, no audio geometry
 };
 
 struct mfcc_stream {
@@ -362,7 +421,7 @@ int32_t mfcc_out_width(const mfcc_plan* p, int32_t out_kind) {
   return fail(MFCC_ERR_INVALID, "out_kind=%d", out_kind);
 }
 
-int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64_t n_utts, mfcc_layout** out) {
+static int layout_create_impl(const mfcc_plan* plan, const int64_t* lengths_host, int64_t n_utts, mfcc_layout** out) {
   if (!plan || !out || n_utts < 0 || (n_utts > 0 && !lengths_host)) return fail(MFCC_ERR_INVALID, "mfcc_layout_create: bad argument");
   if (n_utts > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "more than 2^31-1 utterances in one layout");
   *out = nullptr;
@@ -420,6 +479,51 @@ int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64
   return MFCC_OK;
 }
 
+int mfcc_layout_create(const mfcc_plan* plan, const int64_t* lengths_host, int64_t n_utts, mfcc_layout** out) {
+  // the host-side tables are std::vectors: no C++ exception may cross the C boundary
+  try {
+    return layout_create_impl(plan, lengths_host, n_utts, out);
+  } catch (const std::bad_alloc&) {
+    return fail(MFCC_ERR_NOMEM, "mfcc_layout_create: out of host memory");
+  }
+}
+
+int mfcc_layout_create_frames(int device, const int64_t* frame_counts_host, int64_t n_utts, mfcc_layout** out) {
+  if (!out || n_utts < 0 || (n_utts > 0 && !frame_counts_host)) return fail(MFCC_ERR_INVALID, "mfcc_layout_create_frames: bad argument");
+  if (n_utts > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "more than 2^31-1 utterances in one layout");
+  *out = nullptr;
+  try {
+    mfcc_layout* l = new (std::nothrow) mfcc_layout();
+    if (!l) return fail(MFCC_ERR_NOMEM, "mfcc_layout_create_frames: out of host memory");
+    l->device = device;
+    l->n_utts = n_utts;
+    l->sample_off.assign(n_utts + 1, 0);
+    l->frame_off.assign(n_utts + 1, 0);
+    for (int64_t u = 0; u < n_utts; ++u) {
+      if (frame_counts_host[u] < 0) {
+        delete l;
+        return fail(MFCC_ERR_INVALID, "utterance %lld has a negative frame count", (long long)u);
+      }
+      l->frame_off[u + 1] = l->frame_off[u] + frame_counts_host[u];
+    }
+    l->total_samples = 0;
+    l->total_frames = l->frame_off[n_utts];
+    l->n_tiles = 0;
+    l->frames_only = true;
+    hipError_t e = hipSetDevice(device);
+    int rc = e == hipSuccess ? MFCC_OK : fail(MFCC_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    if (!rc) rc = upload(l->frame_off, &l->d_frame_off);
+    if (rc) {
+      mfcc_layout_destroy(l);
+      return rc;
+    }
+    *out = l;
+    return MFCC_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(MFCC_ERR_NOMEM, "mfcc_layout_create_frames: out of host memory");
+  }
+}
+
 int mfcc_layout_destroy(mfcc_layout* l) {
   if (!l) return MFCC_OK;
   (void)hipFree(l->d_sample_off);
@@ -448,6 +552,7 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
                  int64_t out_ld, int32_t out_kind, void* stream) {
   if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward: null plan or layout");
   if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
+  if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_forward: the layout holds frame counts only (mfcc_layout_create_frames)");
   if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
   const int32_t width = mfcc_out_width(plan, out_kind);
   if (width < 0) return width;
@@ -555,6 +660,7 @@ int mfcc_copy_cols(const float* src, int64_t src_ld, float* dst, int64_t dst_ld,
 int mfcc_fir(const mfcc_layout* layout, const void* audio, int32_t audio_dtype, const float* taps_host, int32_t ntaps, int32_t delay,
              float* out, void* stream) {
   if (!layout || !taps_host) return fail(MFCC_ERR_INVALID, "mfcc_fir: null argument");
+  if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_fir: the layout holds frame counts only (mfcc_layout_create_frames)");
   if (ntaps < 1 || ntaps > 32 || delay < 0 || delay >= ntaps) return fail(MFCC_ERR_INVALID, "mfcc_fir: 1..32 taps, 0 <= delay < ntaps");
   if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
   if (layout->total_samples == 0) return MFCC_OK;
@@ -576,21 +682,31 @@ int mfcc_fir(const mfcc_layout* layout, const void* audio, int32_t audio_dtype, 
   return MFCC_OK;
 }
 
-int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t feats_ld, int32_t ncol, int32_t framenum, float* out,
-                       void* stream) {
+int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t feats_ld, int32_t ncol, int32_t framenum,
+                       int32_t out_layout, const int64_t* row_index, int64_t n_out, float* out, void* stream) {
   if (!layout) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: null layout");
   if (ncol < 1 || feats_ld < ncol || framenum < 1) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: bad shape");
   if (framenum % 2 == 0)
     return fail(MFCC_ERR_INVALID, "framenum=%d: use an odd number of frames (MLP_5hidlayer_40.py:261-262 warns the same)", framenum);
-  if (layout->total_frames == 0) return MFCC_OK;
+  if (out_layout != MFCC_STACK_FRAME_MAJOR && out_layout != MFCC_STACK_TILE) return fail(MFCC_ERR_INVALID, "out_layout=%d", out_layout);
+  if (!row_index) n_out = layout->total_frames;
+  if (n_out < 0) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: n_out=%lld", (long long)n_out);
+  if (layout->total_frames == 0 || n_out == 0) return MFCC_OK;
   if (!feats || !out) return fail(MFCC_ERR_INVALID, "mfcc_stack_context: null pointer");
-  if (layout->total_frames > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_stack_context: more than 2^31-1 rows per call");
-  if (((uintptr_t)out & 15) == 0 && (int64_t)framenum * ncol * mfcc::kStackRows < (1 << 24)) {
+  if (layout->total_frames > INT32_MAX || n_out > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_stack_context: more than 2^31-1 rows per call");
+  hipStream_t st = (hipStream_t)stream;
+  if (out_layout == MFCC_STACK_TILE || row_index) {
+    const size_t smem = (size_t)framenum * (ncol | 1) * sizeof(float);
+    if (smem > 64 * 1024) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_stack_context: framenum * ncol = %d exceeds the 16384 values a window may hold "
+                                      "in this layout / order", framenum * ncol);
+    hipLaunchKernelGGL(mfcc::stack_context_gather_kernel, dim3((unsigned)n_out), dim3(256), smem, st, feats, feats_ld, ncol, framenum,
+                       layout->d_frame_off, (int)layout->n_utts, layout->total_frames, row_index, out_layout == MFCC_STACK_TILE ? 1 : 0, out);
+  } else if (((uintptr_t)out & 15) == 0 && (int64_t)framenum * ncol * mfcc::kStackRows < (1 << 24)) {
     const int64_t nblk = ((layout->total_frames + mfcc::kStackRows - 1) / mfcc::kStackRows + 7) / 8 * 8;  // whole rounds over the 8 XCDs
-    hipLaunchKernelGGL(mfcc::stack_context_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, feats, feats_ld, ncol,
+    hipLaunchKernelGGL(mfcc::stack_context_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, st, feats, feats_ld, ncol,
                        framenum, layout->d_frame_off, (int)layout->n_utts, out, layout->total_frames);
   } else {
-    hipLaunchKernelGGL(mfcc::stack_context_kernel, dim3((unsigned)layout->total_frames), dim3(256), 0, (hipStream_t)stream, feats, feats_ld,
+    hipLaunchKernelGGL(mfcc::stack_context_kernel, dim3((unsigned)layout->total_frames), dim3(256), 0, st, feats, feats_ld,
                        ncol, framenum, layout->d_frame_off, (int)layout->n_utts, out);
   }
   HIP_TRY(hipGetLastError());
@@ -601,15 +717,13 @@ int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, i
   if (n_rows < 0 || ncol < 1 || ncol > 1024 || feats_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate: bad shape");
   if (n_rows == 0) return MFCC_OK;
   if (!feats || !sums) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate: null pointer");
-  int threads = 256;
-  while (threads < ncol) threads += 64;
-  const int64_t rows_per_block = 512;
-  const int64_t nblk = (n_rows + rows_per_block - 1) / rows_per_block;
-  if (nblk > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_cmvn_accumulate: too many rows per call");
-  hipLaunchKernelGGL(mfcc::cmvn_accumulate_kernel, dim3((unsigned)nblk), dim3(threads), 2 * threads * sizeof(double), (hipStream_t)stream,
-                     feats, feats_ld, n_rows, ncol, rows_per_block, sums);
-  HIP_TRY(hipGetLastError());
-  return MFCC_OK;
+  int nblk;
+  int64_t rpb;
+  cmvn_split(n_rows, &nblk, &rpb);
+  double* partial = nullptr;
+  const int rc = cmvn_workspace((hipStream_t)stream, (size_t)mfcc::kCmvnMaxBlocks * 2 * ncol * sizeof(double), &partial);
+  if (rc) return rc;
+  return launch_cmvn(feats, feats_ld, n_rows, ncol, sums, partial, nblk, rpb, (hipStream_t)stream);
 }
 
 int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, const float* mm, const float* vv, void* stream) {
@@ -662,6 +776,10 @@ int mfcc_stream_create(const mfcc_plan* plan, int32_t n_streams, int32_t max_chu
   if (max_chunk < 1 || max_chunk > (1 << 24)) return fail(MFCC_ERR_INVALID, "max_chunk=%d outside 1..2^24", max_chunk);
   if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
   if (plan->cfg.pad_fac != 2) return fail(MFCC_ERR_UNSUPPORTED, "streaming implements pad_fac=2");
+  // the emit kernel indexes (stream, row, coefficient) with 32 bits
+  if ((int64_t)n_streams * (max_chunk / plan->frame_step + 2 + 2 * mfcc::kHalo) * mfcc::kMaxCep >= ((int64_t)1 << 31))
+    return fail(MFCC_ERR_UNSUPPORTED, "n_streams * rows per push = %d * %d exceeds what one emit launch indexes; use fewer streams "
+                "or smaller chunks", n_streams, max_chunk / plan->frame_step + 2 + 2 * mfcc::kHalo);
   if (plan->cfg.frame_rule != 0) return fail(MFCC_ERR_UNSUPPORTED, "streaming implements frame_rule=0 (zero-padded last frame)");
   HIP_TRY(hipSetDevice(plan->device));
   mfcc_stream* s = new (std::nothrow) mfcc_stream();

@@ -289,17 +289,65 @@ __global__ void __launch_bounds__(256) stack_context_rows_kernel(const float* __
   }
 }
 
-// sums[0] += rows, sums[1+c] += sum x, sums[1+D+c] += sum x^2, all in float64.
-// Each workgroup reduces a slab of rows in registers/LDS and issues one atomic per column.
-__global__ void cmvn_accumulate_kernel(const float* __restrict__ x, int64_t ld, int64_t n_rows, int ncol,
-                                       int64_t rows_per_block, double* __restrict__ sums) {
+// Context stacking in its general form: output row i holds the window of stacked row
+// t = row_index ? row_index[i] : i, in one of two element orders:
+//   frame-major  out[i, f*C + c]   (the MLP vector, MLP_5hidlayer_40.py:101-102)
+//   tile         out[i, c*N + f]   (the [C, N] slice paddeddata[:, pos:pos+framenum] the CNN
+//                                   scripts keep, CNN_DenseNet40_6.py:98; row_index carries their
+//                                   shuffled window order, :91-97)
+// One workgroup per output row: the N source rows go through LDS so that both the reads and
+// the (transposed) writes are contiguous.
+__global__ void __launch_bounds__(256) stack_context_gather_kernel(const float* __restrict__ feats, int64_t feats_ld, int ncol,
+                                                                   int framenum, const int64_t* __restrict__ frame_off,
+                                                                   int n_utts, int64_t total_rows,
+                                                                   const int64_t* __restrict__ row_index, int tile_layout,
+                                                                   float* __restrict__ out) {
+  extern __shared__ float win[];  // [N][pitch]
+  const int pitch = ncol | 1;     // odd pitch: the transposed read walks all banks
+  int64_t row = row_index ? row_index[blockIdx.x] : (int64_t)blockIdx.x;
+  row = row < 0 ? 0 : (row > total_rows - 1 ? total_rows - 1 : row);  // a bad index must not fault
+  const int u = utt_of_row(frame_off, n_utts, row);
+  const int64_t f0 = frame_off[u], f1 = frame_off[u + 1];
+  const int half = (framenum - 1) / 2;
+  const int width = framenum * ncol;
+  for (int e = threadIdx.x; e < width; e += 256) {
+    const int f = e / ncol, c = e - f * ncol;
+    int64_t t = row + f - half;
+    t = t < f0 ? f0 : (t > f1 - 1 ? f1 - 1 : t);
+    win[f * pitch + c] = feats[t * feats_ld + c];
+  }
+  __syncthreads();
+  float* const o = out + (int64_t)blockIdx.x * width;
+  if (tile_layout) {
+    for (int e = threadIdx.x; e < width; e += 256) {
+      const int c = e / framenum, f = e - c * framenum;
+      o[e] = win[f * pitch + c];
+    }
+  } else {
+    for (int e = threadIdx.x; e < width; e += 256) {
+      const int f = e / ncol, c = e - f * ncol;
+      o[e] = win[f * pitch + c];
+    }
+  }
+}
+
+// CMVN statistics, float64, bit-reproducible: no cross-workgroup atomics anywhere.
+//   stage 1  workgroup b reduces the rows [b*rows_per_block, (b+1)*rows_per_block) of x and writes
+//            its column sums and sums of squares to partial[b][0 .. 2*ncol);
+//   stage 2  workgroup c adds partial[0 .. nblk)[c] in an order fixed by the code (a strided
+//            sweep per thread, then a fixed pairwise tree) and adds the total into sums[1 + c];
+//            the row count goes to sums[0].
+// Every launch therefore produces the same bits for the same input, whatever the timing.
+constexpr int kCmvnMaxBlocks = 1024;  // stage-1 workgroups at most (bounds the partials scratch)
+
+__global__ void cmvn_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t n_rows, int ncol,
+                                    int64_t rows_per_block, double* __restrict__ partial) {
   extern __shared__ double red[];  // [2][blockDim.x]
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
   // thread (ty, c): c = column handled, ty = row phase
-  const int cols_pad = ncol;
-  const int nphase = blockDim.x / cols_pad;
-  const int c = threadIdx.x % cols_pad, ty = threadIdx.x / cols_pad;
+  const int nphase = blockDim.x / ncol;
+  const int c = threadIdx.x % ncol, ty = threadIdx.x / ncol;
   double s = 0.0, ss = 0.0;
   if (ty < nphase) {
     for (int64_t r = r0 + ty; r < r1; r += nphase) {
@@ -311,16 +359,34 @@ __global__ void cmvn_accumulate_kernel(const float* __restrict__ x, int64_t ld, 
   red[threadIdx.x] = s;
   red[blockDim.x + threadIdx.x] = ss;
   __syncthreads();
-  if (threadIdx.x < ncol) {
+  if ((int)threadIdx.x < ncol) {
     double a = 0.0, b = 0.0;
-    for (int y = 0; y < nphase; ++y) {  // fixed order: deterministic per block
-      a += red[y * cols_pad + threadIdx.x];
-      b += red[blockDim.x + y * cols_pad + threadIdx.x];
+    for (int y = 0; y < nphase; ++y) {  // fixed order
+      a += red[y * ncol + threadIdx.x];
+      b += red[blockDim.x + y * ncol + threadIdx.x];
     }
-    atomicAdd(&sums[1 + threadIdx.x], a);
-    atomicAdd(&sums[1 + ncol + threadIdx.x], b);
+    double* const p = partial + (int64_t)blockIdx.x * 2 * ncol;
+    p[threadIdx.x] = a;
+    p[ncol + threadIdx.x] = b;
   }
-  if (threadIdx.x == 0) atomicAdd(&sums[0], (double)(r1 - r0));
+}
+
+__global__ void __launch_bounds__(256) cmvn_finish_kernel(const double* __restrict__ partial, int nblk, int ncol,
+                                                          int64_t n_rows, double* __restrict__ sums) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;  // 0 .. 2*ncol-1
+  double a = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) a += partial[(int64_t)b * 2 * ncol + c];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[1 + c] += red[0];
+    if (c == 0) sums[0] += (double)n_rows;
+  }
 }
 
 // (x + mm) .* vv in place (the form of anal_recog_nn_liste.m:180).  A workgroup owns a slab of

@@ -46,15 +46,35 @@ def Preprocess(framenum, randbatnum, dataset_name, path, randomint):
     return F.slidingWin(framenum, paddedlabel, paddeddata, randomint)
 
 
-def Databuffer(buffersamples, framenum, dataset_name, path, randomint):
-    """MLP_5hidlayer_40.py:163-172: the first ``buffersamples`` utterances, concatenated."""
-    labelbuffer, vectors = [], []
+def load_utterances(buffersamples, dataset_name, path):
+    """Read the first ``buffersamples`` .pat files and label files (MLP_5hidlayer_40.py:150-156)
+    into one packed host array: (feats [sum F, C] float32, frame_counts, labels per utterance).
+    A label file one entry longer than its utterance loses the last entry, as padUtterance
+    does (:72-73)."""
+    feats, counts, labels = [], [], []
     for pos in range(buffersamples):
-        labellist, datavectorlist = Preprocess(framenum, pos, dataset_name, path, randomint)
-        labelbuffer = labelbuffer + list(labellist)
-        vectors.append(np.asarray(datavectorlist))
-    datavectorbuffer = np.concatenate(vectors, axis=0) if vectors else np.zeros((0, 0), np.float32)
-    return labelbuffer, datavectorbuffer
+        data = F.loadPatData(path + data_dir + dataset_name[pos], 12)          # [C, F]
+        lab = np.loadtxt(path + label_dir + dataset_name[pos][:-4] + ".txt")
+        if lab.shape[0] != data.shape[1]:
+            lab = lab[0:-1]
+        feats.append(np.ascontiguousarray(data.T))
+        counts.append(data.shape[1])
+        labels.append(lab)
+    packed = np.concatenate(feats) if feats else np.zeros((0, F.coeffs), np.float32)
+    return packed, counts, labels
+
+
+def Databuffer(buffersamples, framenum, dataset_name, path, randomint):
+    """MLP_5hidlayer_40.py:163-172: the first ``buffersamples`` utterances, windowed and
+    concatenated -> (labelbuffer, datavectorbuffer [sum F, framenum*C]).  The whole buffer is one
+    host-to-device copy, one stacking launch over the ragged batch and one copy back; the values
+    equal calling Preprocess per utterance.  ``randomint`` is accepted and, like the permutation
+    the reference computes from it (:94-96), not applied."""
+    packed, counts, labels = load_utterances(buffersamples, dataset_name, path)
+    if not counts:
+        return [], np.zeros((0, 0), np.float32)
+    labelbuffer = [v for lab in labels for v in lab]   # centre label of window t = label of frame t
+    return labelbuffer, F.stack_context(packed, framenum, frame_counts=counts)
 
 
 def createMinibatchData(minibatchsize, framenum, datavectorbuffer):

@@ -52,7 +52,22 @@ def _device(device=None):
         raise RuntimeError("mfcc_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
     if device is None:
         return torch.device("cuda", torch.cuda.current_device())
-    return torch.device(device)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError(f"mfcc_amd runs on HIP devices only, got {dev}")
+    if dev.index is None:   # 'cuda' = the current device
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _on(dev, *tensors):
+    """Context for one launch on ``dev``: every tensor handed to the library must live there,
+    and the device is made current so that the stream passed down is that device's current
+    stream (a kernel enqueued on another device's stream would dereference foreign memory)."""
+    for t in tensors:
+        if t is not None and t.device != dev:
+            raise ValueError(f"tensor on {t.device}, but the plan / layout / other operands live on {dev}")
+    return torch.cuda.device(dev)
 
 
 def _stream_ptr():
@@ -165,6 +180,7 @@ class Layout:
     def __init__(self, plan, lengths):
         lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64).reshape(-1))
         self.plan = plan
+        self.device = plan.device
         self.lengths = lengths
         lib = capi.load()
         h = C.c_void_p()
@@ -182,13 +198,21 @@ class Layout:
         self.sample_offsets, self.frame_offsets = so, fo
 
     @classmethod
-    def from_frame_counts(cls, plan, frame_counts):
-        """Layout whose utterances have the given FRAME counts (for stacking features
-        that did not come from audio, e.g. .pat files)."""
-        fc = np.asarray(frame_counts, dtype=np.int64).reshape(-1)
-        lengths = (fc - 1) * plan.frame_step + plan.frame_size
-        lay = cls(plan, lengths)
-        assert np.array_equal(np.diff(lay.frame_offsets), fc)
+    def from_frame_counts(cls, plan_or_device, frame_counts):
+        """Layout whose utterances have the given FRAME counts (>= 0), for feature rows that
+        did not come from audio (e.g. .pat files).  Holds frame offsets only."""
+        dev = plan_or_device.device if isinstance(plan_or_device, Plan) else _device(plan_or_device)
+        fc = np.ascontiguousarray(np.asarray(frame_counts, dtype=np.int64).reshape(-1))
+        lay = cls.__new__(cls)
+        lay.plan, lay.device, lay.lengths = None, dev, None
+        lib = capi.load()
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            capi.check(lib.mfcc_layout_create_frames(dev.index, fc.ctypes.data_as(C.POINTER(C.c_int64)), len(fc), C.byref(h)))
+        lay._h = h
+        lay.n_utts, lay.total_samples, lay.total_frames = len(fc), 0, int(fc.sum())
+        lay.sample_offsets = np.zeros(len(fc) + 1, dtype=np.int64)
+        lay.frame_offsets = np.concatenate([[0], np.cumsum(fc)]).astype(np.int64)
         return lay
 
     def __del__(self):
@@ -253,8 +277,11 @@ class MFCC:
                     or out.shape[1] < width or out.stride(1) != 1):
                 raise ValueError("out must be a float32 device tensor [total_frames, >=width] with unit column stride")
         code = capi.AUDIO_I16 if audio.dtype == torch.int16 else capi.AUDIO_F32
-        capi.check(capi.load().mfcc_forward(self.plan._h, layout._h, _ptr(audio), code, _ptr(out), out.stride(0),
-                                            _OUT_KINDS[kind], _stream_ptr()))
+        if layout.device != self.plan.device:
+            raise ValueError(f"layout on {layout.device}, plan on {self.plan.device}")
+        with _on(self.plan.device, audio, out):
+            capi.check(capi.load().mfcc_forward(self.plan._h, layout._h, _ptr(audio), code, _ptr(out), out.stride(0),
+                                                _OUT_KINDS[kind], _stream_ptr()))
         return out
 
     def __call__(self, audio, lengths=None, out=None, kind="mfcc39"):
@@ -293,10 +320,29 @@ def spectrum257(audio, lengths=None, preemph=0.97, spectrum="power", window=None
 _frame_layouts = {}
 
 
-def stack_context(feats, framenum, frame_counts=None, out=None):
-    """[sum F, C] -> [sum F, framenum*C], frame-major with edge replication per utterance:
-    out[t, f*C + c] = feats[clamp(t + f - (N-1)//2), c]   (padUtterance + slidingWin,
-    MLP_5hidlayer_40.py:70-105)."""
+def frames_layout(device, frame_counts):
+    """Cached frame-count layout (building one uploads an offset table: keep it for repeated
+    batch shapes)."""
+    dev = _device(device)
+    fc = np.ascontiguousarray(np.asarray(frame_counts, dtype=np.int64).reshape(-1))
+    key = (dev.index, fc.tobytes())
+    lay = _frame_layouts.get(key)
+    if lay is None:
+        if len(_frame_layouts) > 64:
+            _frame_layouts.clear()
+        lay = _frame_layouts[key] = Layout.from_frame_counts(dev, fc)
+    return lay
+
+
+def stack_context(feats, framenum, frame_counts=None, out=None, layout="frame_major", order=None):
+    """[sum F, C] -> stacked windows with edge replication per utterance (padUtterance +
+    slidingWin).  ``layout='frame_major'`` gives [n, framenum*C] with
+    out[t, f*C + c] = feats[clamp(t + f - (N-1)//2), c] (the MLP vector, MLP_5hidlayer_40.py:70-105);
+    ``layout='tile'`` gives [n, C, framenum], the [C, N] slice the CNN scripts keep
+    (CNN_DenseNet40_6.py:98).  ``order`` (int64 rows of the packed array) selects and orders the
+    output rows, e.g. the shuffled window order of CNN_DenseNet40_6.py:91-97; default all rows."""
+    if layout not in ("frame_major", "tile"):
+        raise ValueError("layout must be 'frame_major' or 'tile'")
     x, was_numpy = _as_rows(feats)
     t = _to_dev(x, torch.float32)
     if t.dim() != 2:
@@ -306,19 +352,24 @@ def stack_context(feats, framenum, frame_counts=None, out=None):
         frame_counts = [n]
     if int(np.sum(frame_counts)) != n:
         raise ValueError("frame_counts do not add up to the number of rows")
-    plan = get_plan(t.device)
-    fc = np.ascontiguousarray(np.asarray(frame_counts, dtype=np.int64).reshape(-1))
-    key = (id(plan), fc.tobytes())
-    lay = _frame_layouts.get(key)
-    if lay is None:   # building a layout uploads offset tables: keep it for repeated batch shapes
-        if len(_frame_layouts) > 16:
-            _frame_layouts.clear()
-        lay = _frame_layouts[key] = Layout.from_frame_counts(plan, fc)
+    lay = frames_layout(t.device, frame_counts)
+    idx = None
+    n_out = n
+    if order is not None:
+        o = np.asarray(order.cpu() if isinstance(order, torch.Tensor) else order, dtype=np.int64).reshape(-1)
+        if len(o) and (o.min() < 0 or o.max() >= n):
+            raise ValueError("order holds row numbers outside the feature array")
+        idx = order.to(t.device).to(torch.int64).contiguous() if isinstance(order, torch.Tensor) else torch.from_numpy(o).to(t.device)
+        n_out = len(o)
+    shape = (n_out, framenum * c) if layout == "frame_major" else (n_out, c, framenum)
     if out is None:
-        out = torch.empty((n, framenum * c), dtype=torch.float32, device=t.device)
-    elif out.shape != (n, framenum * c) or out.dtype != torch.float32 or not out.is_contiguous():
-        raise ValueError("out must be a contiguous float32 [frames, framenum*coeffs] device tensor")
-    capi.check(capi.load().mfcc_stack_context(lay._h, _ptr(t), t.stride(0), c, int(framenum), _ptr(out), _stream_ptr()))
+        out = torch.empty(shape, dtype=torch.float32, device=t.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous float32 {shape} device tensor")
+    with _on(t.device, out, idx):
+        capi.check(capi.load().mfcc_stack_context(
+            lay._h, _ptr(t), t.stride(0), c, int(framenum), capi.STACK_FRAME_MAJOR if layout == "frame_major" else capi.STACK_TILE,
+            _ptr(idx) if idx is not None else None, n_out, _ptr(out), _stream_ptr()))
     return _ret(out, was_numpy)
 
 
@@ -368,7 +419,7 @@ class StreamingMFCC:
         if out is None:
             out = self._out()
         k = C.c_int32(0)
-        with torch.cuda.device(self.plan.device):
+        with _on(self.plan.device, out):
             # a single row may carry any stride in its size-1 dimension
             ld = max(t.stride(0), t.shape[1]) if self.n_streams == 1 else t.stride(0)
             capi.check(capi.load().mfcc_stream_push(self._h, _ptr(t), ld, t.shape[1],
@@ -379,7 +430,7 @@ class StreamingMFCC:
         if out is None:
             out = self._out()
         k = C.c_int32(0)
-        with torch.cuda.device(self.plan.device):
+        with _on(self.plan.device, out):
             capi.check(capi.load().mfcc_stream_flush(self._h, _ptr(out), out.stride(0), out.stride(1), C.byref(k),
                                                      _stream_ptr()))
         return _ret(out[:, :k.value], as_numpy)
@@ -401,22 +452,35 @@ class StreamingMFCC:
 # --------------------------------------------------------------------------
 def cmvn_accumulate(feats, sums=None):
     """Adds (n, sum x, sum x^2) of the rows of ``feats`` into the float64 device vector
-    ``sums`` of length 1 + 2*D (allocated and zeroed when None)."""
+    ``sums`` of length 1 + 2*D (allocated and zeroed when None).  The reduction order is fixed,
+    so equal inputs give bit-identical sums."""
     if not feats.is_cuda or feats.dtype != torch.float32 or feats.dim() != 2 or feats.stride(1) != 1:
         raise ValueError("feats must be a float32 device tensor [rows, D] with unit column stride")
     n, d = feats.shape
     if sums is None:
         sums = torch.zeros(1 + 2 * d, dtype=torch.float64, device=feats.device)
-    capi.check(capi.load().mfcc_cmvn_accumulate(_ptr(feats), feats.stride(0), n, d, _ptr(sums), _stream_ptr()))
+    elif sums.dtype != torch.float64 or sums.numel() != 1 + 2 * d or not sums.is_contiguous():
+        raise ValueError("sums must be a contiguous float64 vector of 1 + 2*D elements")
+    lib = capi.load()
+    fn = lib.mfcc_cmvn_accumulate
+    with _on(feats.device, sums):
+        capi.check(fn(_ptr(feats), feats.stride(0), n, d, _ptr(sums), _stream_ptr()))
     return sums
 
 
 def cmvn_allreduce(sums, group=None):
-    """Sum the CMVN statistics over all ranks (RCCL all-reduce of 1 + 2*D doubles; the
-    only collective of the front-end).  A no-op without an initialised process group."""
+    """Combine the CMVN statistics of all ranks (the only collective of the front-end, 1 + 2*D
+    doubles per rank over RCCL): an all-gather followed by a sum in rank order on every rank, so
+    the constants are bit-identical on all ranks and from run to run -- an all-reduce leaves the
+    order of the additions to the collective's algorithm.  A no-op without a process group."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        parts = [torch.empty_like(sums) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, sums.contiguous(), group=group)
+        total = parts[0].clone()
+        for p in parts[1:]:
+            total += p
+        sums.copy_(total)
     return sums
 
 
@@ -433,7 +497,11 @@ def cmvn_constants(sums, ddof=0):
 def cmvn_apply(feats, mm, vv):
     """In place: feats = (feats + mm) * vv."""
     n, d = feats.shape
-    capi.check(capi.load().mfcc_cmvn_apply(_ptr(feats), feats.stride(0), n, d, _ptr(mm), _ptr(vv), _stream_ptr()))
+    if mm.numel() != d or vv.numel() != d or mm.dtype != torch.float32 or vv.dtype != torch.float32:
+        raise ValueError("mm and vv must be float32 vectors of D elements")
+    with _on(feats.device, mm, vv):
+        capi.check(capi.load().mfcc_cmvn_apply(_ptr(feats), feats.stride(0), n, d, _ptr(mm.contiguous()), _ptr(vv.contiguous()),
+                                               _stream_ptr()))
     return feats
 
 
@@ -469,7 +537,8 @@ def preemphasis(signal, coeff=0.97):
     t, code, was_numpy = _audio_tensor(signal)
     t = t.reshape(-1)
     out = torch.empty(t.numel(), dtype=torch.float32, device=t.device)
-    capi.check(capi.load().mfcc_preemphasis(_ptr(t), code, t.numel(), float(coeff), _ptr(out), _stream_ptr()))
+    with _on(t.device, out):
+        capi.check(capi.load().mfcc_preemphasis(_ptr(t), code, t.numel(), float(coeff), _ptr(out), _stream_ptr()))
     return _ret(out, was_numpy)
 
 
@@ -510,7 +579,8 @@ def melspec(powfft_list, melbank):
         raise ValueError(f"shapes {tuple(spec.shape)} and {tuple(bank.T.shape)} not aligned")
     logmel = torch.empty((n, nmel), dtype=torch.float32, device=spec.device)
     loge = torch.empty(n, dtype=torch.float32, device=spec.device)
-    capi.check(capi.load().mfcc_melspec(_ptr(spec), n, k, _ptr(bank), nmel, 0, _ptr(logmel), _ptr(loge), _stream_ptr()))
+    with _on(spec.device, bank):
+        capi.check(capi.load().mfcc_melspec(_ptr(spec), n, k, _ptr(bank), nmel, 0, _ptr(logmel), _ptr(loge), _stream_ptr()))
     return _ret(logmel, was_numpy), _ret(loge, was_numpy)
 
 
@@ -520,7 +590,8 @@ def mfcc(melspec_list, numcep=12):
     lm = _to_dev(x, torch.float32)
     n, nmel = lm.shape
     out = torch.empty((n, int(numcep)), dtype=torch.float32, device=lm.device)
-    capi.check(capi.load().mfcc_dct(_ptr(lm), n, nmel, int(numcep), _ptr(out), _stream_ptr()))
+    with _on(lm.device):
+        capi.check(capi.load().mfcc_dct(_ptr(lm), n, nmel, int(numcep), _ptr(out), _stream_ptr()))
     return _ret(out, was_numpy)
 
 
@@ -530,7 +601,8 @@ def dctopt(mfcc_list, lift_factor=22):
     c = _to_dev(x, torch.float32)
     n, k = c.shape
     out = torch.empty_like(c)
-    capi.check(capi.load().mfcc_lifter(_ptr(c), n, k, float(lift_factor), _ptr(out), _stream_ptr()))
+    with _on(c.device):
+        capi.check(capi.load().mfcc_lifter(_ptr(c), n, k, float(lift_factor), _ptr(out), _stream_ptr()))
     return _ret(out, was_numpy)
 
 
@@ -544,8 +616,9 @@ def staticfeatures(energy_list, mfcclift_list):
     n, k = c.shape
     out = torch.empty_like(c)
     lib = capi.load()
-    capi.check(lib.mfcc_copy_cols(_ptr(c), c.stride(0), _ptr(out), out.stride(0), n, k, _stream_ptr()))
-    capi.check(lib.mfcc_copy_cols(_ptr(e), 1, _ptr(out), out.stride(0), n, 1, _stream_ptr()))
+    with _on(c.device, e):
+        capi.check(lib.mfcc_copy_cols(_ptr(c), c.stride(0), _ptr(out), out.stride(0), n, k, _stream_ptr()))
+        capi.check(lib.mfcc_copy_cols(_ptr(e), 1, _ptr(out), out.stride(0), n, 1, _stream_ptr()))
     return _ret(out, was_numpy)
 
 
@@ -555,7 +628,8 @@ def delta(features, pad_fac=2):
     f = _to_dev(x, torch.float32)
     n, k = f.shape
     out = torch.empty_like(f)
-    capi.check(capi.load().mfcc_delta(_ptr(f), n, k, int(pad_fac), _ptr(out), _stream_ptr()))
+    with _on(f.device):
+        capi.check(capi.load().mfcc_delta(_ptr(f), n, k, int(pad_fac), _ptr(out), _stream_ptr()))
     return _ret(out, was_numpy)
 
 
@@ -565,7 +639,7 @@ def spectrograms(cepstrum, delta_features, delta_delta_features):
     for p in (cepstrum, delta_features, delta_delta_features):
         x, wn = _as_rows(p)
         was_numpy = was_numpy and wn
-        parts.append(_to_dev(x, torch.float32))
+        parts.append(_to_dev(x, torch.float32, parts[0].device if parts else None))
     n = parts[0].shape[0]
     width = sum(p.shape[1] for p in parts)
     out = torch.empty((n, width), dtype=torch.float32, device=parts[0].device)
@@ -573,7 +647,8 @@ def spectrograms(cepstrum, delta_features, delta_delta_features):
     lib = capi.load()
     for p in parts:
         dst = C.c_void_p(out.data_ptr() + 4 * col)
-        capi.check(lib.mfcc_copy_cols(_ptr(p), p.stride(0), dst, out.stride(0), n, p.shape[1], _stream_ptr()))
+        with _on(out.device, p):
+            capi.check(lib.mfcc_copy_cols(_ptr(p), p.stride(0), dst, out.stride(0), n, p.shape[1], _stream_ptr()))
         col += p.shape[1]
     return _ret(out, was_numpy)
 

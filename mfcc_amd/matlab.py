@@ -34,8 +34,9 @@ def fir_centered(audio, lengths, taps, delay, plan=None):
     taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float32))
     out = torch.empty(audio.numel(), dtype=torch.float32, device=audio.device)
     code = capi.AUDIO_I16 if audio.dtype == torch.int16 else capi.AUDIO_F32
-    capi.check(capi.load().mfcc_fir(lay._h, F._ptr(audio), code, taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps),
-                                    int(delay), F._ptr(out), F._stream_ptr()))
+    with F._on(plan.device, audio):
+        capi.check(capi.load().mfcc_fir(lay._h, F._ptr(audio), code, taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps),
+                                        int(delay), F._ptr(out), F._stream_ptr()))
     return out
 
 

@@ -12,14 +12,14 @@ import numpy as np
 import torch
 
 from . import _capi as capi
-from .frontend import MFCC, Layout, _ptr, _stream_ptr, get_plan
+from .frontend import MFCC, _on, _ptr, _stream_ptr, frames_layout
 
 
 def _frames_layout(feats, frame_counts):
     frame_counts = np.asarray(frame_counts, dtype=np.int64).reshape(-1)
     if int(frame_counts.sum()) != feats.shape[0]:
         raise ValueError("frame_counts do not add up to the number of rows")
-    return Layout.from_frame_counts(get_plan(feats.device), frame_counts), frame_counts
+    return frames_layout(feats.device, frame_counts), frame_counts
 
 
 def utterance_scalar_norm(feats, frame_counts):
@@ -28,7 +28,8 @@ def utterance_scalar_norm(feats, frame_counts):
     if not feats.is_cuda or feats.dtype != torch.float32 or feats.dim() != 2 or feats.stride(1) != 1:
         raise ValueError("feats must be a float32 device tensor [rows, D] with unit column stride")
     lay, _ = _frames_layout(feats, frame_counts)
-    capi.check(capi.load().mfcc_utt_scalar_norm(lay._h, _ptr(feats), feats.stride(0), feats.shape[1], _stream_ptr()))
+    with _on(feats.device):
+        capi.check(capi.load().mfcc_utt_scalar_norm(lay._h, _ptr(feats), feats.stride(0), feats.shape[1], _stream_ptr()))
     return feats
 
 
@@ -52,15 +53,17 @@ def pad_sequences(feats, frame_counts, maxlen=None, padding="post", truncating="
     elif tuple(out.shape) != (b, maxlen, d) or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError("out must be a contiguous float32 [B, maxlen, D] device tensor")
     if b and maxlen:
-        capi.check(capi.load().mfcc_pad_batch(lay._h, _ptr(feats), feats.stride(0), d, int(maxlen), float(value),
-                                              int(padding == "pre"), int(truncating == "pre"), _ptr(out), _stream_ptr()))
+        with _on(feats.device, out):
+            capi.check(capi.load().mfcc_pad_batch(lay._h, _ptr(feats), feats.stride(0), d, int(maxlen), float(value),
+                                                  int(padding == "pre"), int(truncating == "pre"), _ptr(out), _stream_ptr()))
     return out, frame_counts.copy()
 
 
 def ctc_feature_batch(audios, variant="self5", time_steps=None, normalize=True, device=None, **overrides):
     """Feature side of create_minibatch_ctc (inference_ctc_eri_05.py:283-300): a list of
     utterances (int16 / float arrays of any lengths) -> (features [B, T, 39], seq_length
-    int64[B]) with per-utterance scalar normalisation and zero padding, in three launches."""
+    int64[B]) with per-utterance scalar normalisation and zero padding: three launches on a
+    repeated batch shape (the offset tables of a new shape are uploaded once and cached)."""
     fe = MFCC(variant, device=device, **overrides)
     lengths = [int(np.asarray(a).shape[-1]) if not isinstance(a, torch.Tensor) else int(a.shape[-1]) for a in audios]
     parts = [a if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a)) for a in audios]

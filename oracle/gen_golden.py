@@ -42,12 +42,13 @@ def load_reference(fname, modname):
     return mod
 
 
-def run_pipeline(mod, audio, variant):
+def run_pipeline(mod, audio, variant, fs=16000, frame_time=None, step_time=None):
     """Drive the reference functions exactly as its main() does."""
-    fs = 16000
+    frame_time = mod.frame_time if frame_time is None else frame_time
+    step_time = mod.step_time if step_time is None else step_time
     audio_pre = mod.preemphasis(audio)
     src = audio_pre if variant == "self5" else audio  # self15:230 feeds the raw signal
-    magfft, powfft, win, nfft = mod.winfft(src, fs, mod.frame_time, mod.step_time)
+    magfft, powfft, win, nfft = mod.winfft(src, fs, frame_time, step_time)
     bank = mod.melbanks(fs, mod.num_bins, mod.low_freq, nfft)
     spec = powfft if variant == "self5" else magfft  # self15:234 feeds magnitudes
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -199,6 +200,59 @@ def main():
             pack[f"{name}_stack{framenum}"] = np.array(veclist, dtype=np.float32)
             pack[f"{name}_stacklab{framenum}"] = np.array(lablist)
     np.savez_compressed(os.path.join(OUT, "stacking.npz"), **pack)
+
+    # ---- 7. the CNN scripts' windows: [C, N] tiles in (optionally) shuffled order ------------
+    #         (CNN_DenseNet40_6.py:59-131; the file builds a TensorFlow graph at import time, so
+    #         only these function definitions are compiled)
+    with open(os.path.join(REF, "CNN_DenseNet40_6.py"), "r", encoding="utf-8", errors="replace") as fh:
+        tree = ast.parse(fh.read())
+    wanted = {"loadPatData", "padUtterance", "slidingWin", "createRandomvec", "createMinibatchData"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in wanted]
+    assert {n.name for n in body} == wanted
+    cns = {"np": np, "os": os, "coeffs": 39}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "CNN_DenseNet40_6.py", "exec"), cns)
+    pack = {}
+    name = "is1c0001_001"
+    path = os.path.join(tmpdir, name + ".pat")
+    data = cns["loadPatData"](path, 12)
+    labels = np.loadtxt(io.BytesIO(labs.read(f"nn_output30/{name}.txt")))
+    pack["name"] = np.array(name)
+    pack["data"] = data
+    pack["labels"] = labels
+    for framenum in (11, 17):
+        for randomint in (-11, 3):
+            plab, pdat = cns["padUtterance"](framenum, labels, data)
+            lablist, tiles = cns["slidingWin"](framenum, plab, pdat, randomint)
+            tag = f"n{framenum}_r{randomint if randomint >= 0 else 'm11'}"
+            pack[f"tiles_{tag}"] = np.array(tiles, dtype=np.float32)          # [F, C, N]
+            pack[f"labels_{tag}"] = np.array(lablist)
+            pack[f"minibatch_{tag}"] = cns["createMinibatchData"](16, framenum, tiles)   # float64 [16, C, N, 1]
+    np.savez_compressed(os.path.join(OUT, "stacking_cnn.npz"), **pack)
+
+    # ---- 8. other frame geometries of winfft (self5:75-84): 8 kHz -> 200/80 samples, 256-point FFT;
+    #         44.1 kHz -> 1102/441, 2048-point; 20 ms frames at 16 kHz -> 320/160, 512-point ------
+    pack = {}
+    geoms = {
+        "8k": dict(fs=8000, frame_time=25, step_time=10, lengths=[1, 199, 200, 201, 281, 8000]),
+        "44k": dict(fs=44100, frame_time=25, step_time=10, lengths=[1, 1102, 1103, 1544, 44100]),
+        "16k_20ms": dict(fs=16000, frame_time=20, step_time=10, lengths=[319, 320, 321, 481, 5000]),
+        "16k_32ms_8ms": dict(fs=16000, frame_time=32, step_time=8, lengths=[512, 513, 4000]),
+    }
+    for gname, gcfg in geoms.items():
+        pack[f"{gname}_lengths"] = np.array(gcfg["lengths"], dtype=np.int64)
+        pack[f"{gname}_cfg"] = np.array([gcfg["fs"], gcfg["frame_time"], gcfg["step_time"]], dtype=np.float64)
+        for i, length in enumerate(gcfg["lengths"]):
+            audio = synth(300 + i, length)
+            pack[f"{gname}_audio_{length}"] = audio
+            for variant, mod in mods.items():
+                st = run_pipeline(mod, audio, variant, gcfg["fs"], gcfg["frame_time"], gcfg["step_time"])
+                pack[f"{gname}_{variant}_out_{length}"] = st["out"]
+                pack[f"{gname}_{variant}_logmel_{length}"] = st["logmel"]
+                pack[f"{gname}_{variant}_loge_{length}"] = st["loge"]
+                pack[f"{gname}_nfft"] = st["nfft"]
+                if i == 1:
+                    pack[f"{gname}_{variant}_spec_{length}"] = st["pow"] if variant == "self5" else st["mag"]
+    np.savez_compressed(os.path.join(OUT, "geometry.npz"), **pack)
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

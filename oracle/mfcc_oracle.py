@@ -256,13 +256,14 @@ def mfcc39(audio, variant="self5", fs=FS, frame_time=FRAME_TIME, step_time=STEP_
     return out
 
 
-def spectrum257(audio, variant="self5", kind=None, log=False, loop=False):
+def spectrum257(audio, variant="self5", kind=None, log=False, loop=False, fs=FS, frame_time=FRAME_TIME,
+                step_time=STEP_TIME, num_fft=None):
     """The 257-bin variant: winfft's per-frame spectrum stacked to [F,257]
     (self5:96-99); optional natural log of it."""
     cfg = VARIANTS[variant]
     audio = np.asarray(audio)
     sig = preemphasis(audio, cfg["preemph"]) if cfg["preemph"] is not None else audio
-    mag, pw, _w, _n = winfft(sig, loop=loop)
+    mag, pw, _w, _n = winfft(sig, fs, frame_time, step_time, loop=loop, num_fft=num_fft)
     spec = pw if (kind or cfg["spectrum"]) == "power" else mag
     if log:
         with np.errstate(divide="ignore"):
@@ -290,6 +291,30 @@ def stack_context(feats, framenum):
         idx = np.clip(np.arange(t - half, t - half + framenum), 0, n_frames - 1)
         rows.append(feats[idx].reshape(-1))
     return np.stack(rows)
+
+
+def stack_context_tiles(feats, framenum, order=None):
+    """The CNN scripts' form of the same windows (CNN_DenseNet40_6.py:86-103): each window is
+    kept as the [C, N] slice paddeddata[:, pos:pos+framenum] (:98), visited in ``order``
+    (createRandomvec(randomint, F) when randomint != -11, :91-97).  Returns [len(order), C, N]:
+    out[i, c, f] = feats[clamp(order[i] + f - (N-1)//2), c]."""
+    feats = np.asarray(feats)
+    n_frames, _c = feats.shape
+    half = int((framenum - 1) / 2)
+    order = np.arange(n_frames) if order is None else np.asarray(order)
+    tiles = []
+    for t in order:
+        idx = np.clip(np.arange(t - half, t - half + framenum), 0, n_frames - 1)
+        tiles.append(feats[idx].T)
+    return np.stack(tiles) if len(tiles) else np.zeros((0, feats.shape[1], framenum), feats.dtype)
+
+
+def random_order(randomint, n):
+    """createRandomvec (MLP_5hidlayer_40.py:107-112, CNN_DenseNet40_6.py:105-110)."""
+    np.random.seed(randomint)
+    vec = np.arange(n)
+    np.random.shuffle(vec)
+    return vec
 
 
 def read_pat(path_or_bytes, coeffs):

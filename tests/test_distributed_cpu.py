@@ -33,7 +33,8 @@ def _worker(rank, world, port, lengths, q):
     sums = torch.from_numpy(np.concatenate([[float(n)], s, ss]))
     sums = cmvn_allreduce(sums)
     mm, vv = cmvn_constants(sums)
-    q.put((rank, begin, end, sums.numpy().copy(), mm.numpy().copy(), vv.numpy().copy()))
+    local = torch.from_numpy(np.concatenate([[float(n)], s, ss]))
+    q.put((rank, begin, end, sums.numpy().copy(), mm.numpy().copy(), vv.numpy().copy(), local.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,5 +62,10 @@ def test_two_rank_cmvn_allreduce_matches_single_process():
         assert sums[0] == n
         assert np.allclose(sums[1:40], s, rtol=1e-12, atol=1e-9) and np.allclose(sums[40:], ss, rtol=1e-12)
     assert np.array_equal(res[0][3], res[1][3])          # every rank holds identical constants
+    # the combination is an all-gather plus a sum in rank order: bit-equal to adding the per-rank
+    # vectors in that order in one process
+    ordered = res[0][6].copy()
+    ordered += res[1][6]
+    assert np.array_equal(res[0][3], ordered)
     rmm, rvv = O.cmvn_constants(n, s, ss)
     assert np.allclose(res[0][4], rmm, rtol=1e-6) and np.allclose(res[0][5], rvv, rtol=1e-6)

@@ -9,8 +9,8 @@ Tolerances (float32 kernels vs the float64 reference):
     60 dB stronger at other frequencies: the rounding noise of a float32 FFT is ~1e-7 of the
     frame's RMS spectrum (scipy.fft.rfft in float32 gives 1.2e-4 on the same entry; numpy's
     float32 FFT is computed in double internally and is not a float32 datum).  The pure
-    relative figure is still measured and bounded: >= 99.9 % of entries within 1e-4 and no
-    entry beyond 1e-3;
+    relative figure is still measured, printed and bounded: >= 99.9 % of entries within 1e-4 and
+    no entry beyond 3e-4 (the worst observed is 2.4e-4, LDC93S1 frame 19 band 1);
   * cepstra, delta, delta-delta (all 39 columns): 1e-3 ABSOLUTE;
   * integer / copy operations (stacking, .pat round trip): bit exact.
 """
@@ -26,6 +26,7 @@ from oracle import mfcc_oracle as O
 pytestmark = pytest.mark.gpu
 
 LOGMEL_RTOL = 1e-4
+LOGMEL_PURE_CAP = 3e-4   # entries where ln-mel crosses zero; worst observed 2.4e-4
 CEP_ATOL = 1e-3
 VARIANTS = ("self5", "self15")
 
@@ -49,8 +50,10 @@ def assert_logmel(gpu, ref, what):
     assert rel.max(initial=0) <= LOGMEL_RTOL, f"{what}: max rel err {rel.max():.3e} at |ref|={np.abs(ref[fin])[rel.argmax()]:.4g}"
     pure = err / np.maximum(np.abs(ref[fin]), 1e-300)
     if pure.size:
+        print(f"[ln-mel] {what}: worst pure relative {pure.max():.3e} (|ref| = {np.abs(ref[fin])[pure.argmax()]:.4g}), "
+              f"{int((pure > LOGMEL_RTOL).sum())} of {pure.size} beyond {LOGMEL_RTOL:g}")
         assert (pure <= LOGMEL_RTOL).mean() >= 0.999, f"{what}: {100 * (pure > LOGMEL_RTOL).mean():.3f} % beyond 1e-4 pure relative"
-        assert pure.max() <= 1e-3, f"{what}: max pure relative err {pure.max():.3e}"
+        assert pure.max() <= LOGMEL_PURE_CAP, f"{what}: max pure relative err {pure.max():.3e}"
     return rel.max(initial=0)
 
 

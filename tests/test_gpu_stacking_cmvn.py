@@ -1,0 +1,202 @@
+"""GPU parity tests of the pieces around the fused kernel: the CNN scripts' window layout and
+shuffled order (bit-exact against goldens from the reference's own CNN slidingWin /
+createMinibatchData), the batched .pat buffers, bit-reproducible CMVN sums, device guards."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mfcc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import mfcc_amd
+    return mfcc_amd
+
+
+def _tag(randomint):
+    return "m11" if randomint == -11 else str(randomint)
+
+
+def test_cnn_tiles_bit_exact(M, golden):
+    """CNN_DenseNet40_6.py:86-131 through the same-named functions of mfcc_amd.cnn."""
+    from mfcc_amd import cnn
+    g = golden("stacking_cnn.npz")
+    data, labels = g["data"], g["labels"]                    # [C, F] like the reference
+    for framenum in (11, 17):
+        for randomint in (-11, 3):
+            plab, pdat = cnn.padUtterance(framenum, labels, data)
+            lablist, tiles = cnn.slidingWin(framenum, plab, pdat, randomint)
+            ref = g[f"tiles_n{framenum}_r{_tag(randomint)}"]
+            tiles = np.asarray(tiles)
+            assert tiles.dtype == np.float32 and tiles.shape == ref.shape == (data.shape[1], 39, framenum)
+            assert np.array_equal(tiles, ref)
+            assert np.array_equal(np.asarray(lablist), g[f"labels_n{framenum}_r{_tag(randomint)}"])
+            mb = cnn.createMinibatchData(16, framenum, tiles)
+            assert mb.dtype == np.float64 and np.array_equal(mb, g[f"minibatch_n{framenum}_r{_tag(randomint)}"])
+    # iterating the datalist gives one [C, N] slice per window, as the reference's list does
+    assert next(iter(tiles)).shape == (39, 17)
+
+
+def test_stack_layouts_orders_and_ragged(M):
+    rng = np.random.default_rng(12)
+    counts = [1, 0, 5, 40, 299, 8]
+    n = sum(counts)
+    for ncol in (39, 257, 4):
+        feats = rng.standard_normal((n, ncol)).astype(np.float32)
+        dev = torch.from_numpy(feats).cuda()
+        ref_fm, ref_tile, r = [], [], 0
+        for c in counts:
+            if c:
+                ref_fm.append(O.stack_context(feats[r:r + c], 17))
+                ref_tile.append(O.stack_context_tiles(feats[r:r + c], 17))
+            r += c
+        ref_fm, ref_tile = np.concatenate(ref_fm), np.concatenate(ref_tile)
+        assert np.array_equal(M.stack_context(dev, 17, frame_counts=counts).cpu().numpy(), ref_fm)
+        tile = M.stack_context(dev, 17, frame_counts=counts, layout="tile").cpu().numpy()
+        assert tile.shape == (n, ncol, 17) and np.array_equal(tile, ref_tile)
+        order = rng.permutation(n)[: n // 2]
+        assert np.array_equal(M.stack_context(dev, 17, frame_counts=counts, layout="tile", order=order).cpu().numpy(), ref_tile[order])
+        assert np.array_equal(M.stack_context(dev, 17, frame_counts=counts, order=torch.from_numpy(order).cuda()).cpu().numpy(), ref_fm[order])
+    with pytest.raises(ValueError):
+        M.stack_context(dev, 17, frame_counts=counts, order=[n])
+    with pytest.raises(ValueError):
+        M.stack_context(dev, 17, frame_counts=counts, layout="rows")
+
+
+def test_batched_databuffers_match_per_utterance(M, golden, tmp_path):
+    """Databuffer (MLP_5hidlayer_40.py:163-172, CNN_DenseNet40_6.py:162-171) as one launch over the
+    packed corpus equals the per-utterance Preprocess calls, and the goldens."""
+    from mfcc_amd import cnn, datasets as D
+    g = golden("stacking.npz")
+    gc = golden("stacking_cnn.npz")
+    root = str(tmp_path) + "/"
+    names = ["is1c0001_001.pat", "is1c0001_031.pat"]
+    os.makedirs(root + D.data_dir, exist_ok=True)
+    os.makedirs(root + D.label_dir, exist_ok=True)
+    for n in names:
+        with open(root + D.data_dir + n, "wb") as fh:
+            fh.write(np.asarray(g[n[:-4] + "_pat_bytes"]).tobytes())
+        np.savetxt(root + D.label_dir + n[:-4] + ".txt", np.asarray(g[n[:-4] + "_labels"]))
+    lb, db = D.Databuffer(2, 17, names, root, -11)
+    assert np.array_equal(db, np.concatenate([g["is1c0001_001_stack17"], g["is1c0001_031_stack17"]]))
+    assert np.array_equal(np.asarray(lb), np.concatenate([g["is1c0001_001_stacklab17"], g["is1c0001_031_stacklab17"]]))
+    for randomint in (-11, 3):
+        lb, tiles = cnn.Databuffer(2, 11, names, root, randomint)
+        per = [cnn.Preprocess(11, i, names, root, randomint) for i in range(2)]
+        assert np.array_equal(tiles, np.concatenate([np.asarray(p[1]) for p in per]))
+        assert np.array_equal(np.asarray(lb), np.concatenate([np.asarray(p[0]) for p in per]))
+        assert np.array_equal(tiles[:gc[f"tiles_n11_r{_tag(randomint)}"].shape[0]], gc[f"tiles_n11_r{_tag(randomint)}"])
+
+
+def test_cmvn_sums_are_bit_reproducible_and_match_float64(M):
+    """Fixed reduction order: two accumulations of the same rows give the same bits; the values
+    equal a float64 numpy reduction to rounding."""
+    rng = np.random.default_rng(8)
+    for n, d in ((70001, 39), (1000, 257), (3, 1), (600000, 39)):
+        x = (rng.standard_normal((n, d)) * 5 + 3).astype(np.float32)
+        t = torch.from_numpy(x).cuda()
+        a = M.cmvn_accumulate(t)
+        b = M.cmvn_accumulate(t)
+        assert torch.equal(a, b)
+        cnt, s, ss = O.cmvn_sums(x)
+        got = a.cpu().numpy()
+        assert got[0] == cnt
+        assert np.allclose(got[1:1 + d], s, rtol=1e-12, atol=1e-6) and np.allclose(got[1 + d:], ss, rtol=1e-12)
+    # accumulation over chunks adds up
+    c = M.cmvn_accumulate(t[:1000])
+    c = M.cmvn_accumulate(t[1000:], c)
+    assert np.allclose(c.cpu().numpy(), got, rtol=1e-13)
+
+
+def test_cmvn_chain_on_mfcc_output(M):
+    """forward -> accumulate -> constants -> apply on the product's own MFCC rows, checked against
+    float64 numpy statistics of the oracle's features (a strided sample of the utterances)."""
+    rng = np.random.default_rng(21)
+    lengths = [int(v) for v in rng.integers(2000, 20000, size=64)]
+    audios = [np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths]
+    fe = M.MFCC("self5")
+    lay = fe.layout(lengths)
+    feats = fe.forward(torch.from_numpy(np.concatenate(audios)).cuda(), lay)
+    sums = M.cmvn_allreduce(M.cmvn_accumulate(feats))          # world size 1: identity
+    mm, vv = M.cmvn_constants(sums)
+    raw = feats.cpu().numpy().astype(np.float64)
+    normed = M.cmvn_apply(feats, mm, vv).cpu().numpy()
+    assert np.abs(normed.mean(0)).max() < 1e-4 and np.abs(normed.std(0) - 1).max() < 1e-4
+    cnt, s, ss = O.cmvn_sums(raw)
+    rmm, rvv = O.cmvn_constants(cnt, s, ss)
+    fo = lay.frame_offsets
+    for u in range(0, 64, 9):
+        ref = O.cmvn_apply(O.mfcc39(audios[u], "self5", loop=False), rmm, rvv)
+        np.testing.assert_allclose(normed[fo[u]:fo[u + 1]], ref, rtol=0, atol=1e-3)   # 1e-3 cepstral tolerance / std (>= 1)
+
+
+def test_frame_layout_accepts_zero_counts_and_rejects_forward(M):
+    from mfcc_amd import sequences
+    counts = [3, 0, 2]
+    x = torch.arange(5 * 4, dtype=torch.float32, device="cuda").reshape(5, 4)
+    pad, lens = sequences.pad_sequences(x, counts, maxlen=3)
+    assert pad.shape == (3, 3, 4) and (pad[1] == 0).all() and np.array_equal(lens, counts)
+    lay = M.frontend.frames_layout("cuda", counts)
+    with pytest.raises(M.frontend.capi.MfccError):
+        M.MFCC("self5").forward(torch.zeros(0, dtype=torch.int16, device="cuda"), lay)
+
+
+def test_device_guards(M):
+    fe = M.MFCC("self5", device="cuda")                      # 'cuda' = the current device
+    assert fe.plan.device.index == torch.cuda.current_device()
+    with pytest.raises(ValueError):
+        M.MFCC("self5", device="cpu")
+    if torch.cuda.device_count() < 2:
+        return
+    rng = np.random.default_rng(1)
+    audio = np.clip(rng.standard_normal(5000) * 3000, -32768, 32767).astype(np.int16)
+    fe1 = M.MFCC("self5", device="cuda:1")
+    out1 = fe1(torch.from_numpy(audio).to("cuda:1"))          # current device stays 0
+    assert out1.device.index == 1 and torch.cuda.current_device() == 0
+    assert np.array_equal(out1.cpu().numpy(), M.MFCC("self5", device="cuda:0")(audio))
+    with pytest.raises(ValueError):
+        fe1.forward(torch.from_numpy(audio).to("cuda:0"), fe1.layout([5000]))
+
+
+def test_loadrawdata_round_trip(M, tmp_path):
+    rng = np.random.default_rng(2)
+    audio = np.clip(rng.standard_normal(1234) * 3000, -32768, 32767).astype(np.int16)
+    path = str(tmp_path / "utt.raw")
+    audio.astype("<i2").tofile(path)
+    back = M.loadrawdata(path)
+    assert back.dtype == np.int16 and np.array_equal(back, audio)
+
+
+def test_streaming_64_streams(M):
+    rng = np.random.default_rng(64)
+    B, L = 64, 2400 + 11
+    audio = np.clip(rng.standard_normal((B, L)) * 3000, -32768, 32767).astype(np.int16)
+    s = M.StreamingMFCC("self5", n_streams=B, max_chunk=160)
+    dev = torch.from_numpy(audio).cuda()
+    parts = [s.push(dev[:, i:i + 160]) for i in range(0, L, 160)] + [s.flush()]
+    got = torch.cat(parts, dim=1).cpu().numpy()
+    for b in (0, 17, 63):
+        ref = O.mfcc39(audio[b], "self5", loop=False)
+        assert got[b].shape == ref.shape and np.abs(got[b] - ref).max() <= 1e-3
+    off = M.MFCC("self5")(dev).cpu().numpy().reshape(B, -1, 39)
+    np.testing.assert_allclose(got, off, rtol=0, atol=2e-5)
+
+
+def test_log_spectrum_against_oracle(M, golden):
+    g = golden("ldc93s1.npz")
+    for variant in ("self5", "self15"):
+        lg = M.spectrum257(g["audio"], log=True, **M.VARIANTS[variant])
+        ref = O.spectrum257(g["audio"], variant, log=True)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(lg), fin)
+        # ln of a float32 spectrum value: the spectrum is good to 2e-6 of the row maximum, so bins
+        # far below the row maximum carry that absolute error into their logarithm
+        spec = np.exp(ref)
+        tol = 2e-6 * spec.max(axis=1, keepdims=True) / np.maximum(spec, 1e-300) + 2e-6 * np.maximum(np.abs(ref), 1)
+        assert (np.abs(lg - ref)[fin] <= tol[fin]).all()

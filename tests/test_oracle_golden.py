@@ -156,3 +156,51 @@ def test_cmvn_helpers():
     mm, vv = O.cmvn_constants(n, s, ss)
     y = O.cmvn_apply(x, mm, vv)
     assert np.allclose(y.mean(0), 0, atol=1e-12) and np.allclose(y.std(0), 1, atol=1e-12)
+
+
+def test_cnn_tiles_and_shuffled_order(golden):
+    """The oracle's tile-form windows against the reference's CNN slidingWin / createMinibatchData
+    (CNN_DenseNet40_6.py:86-131), plain and shuffled."""
+    g = golden("stacking_cnn.npz")
+    feats = np.ascontiguousarray(g["data"].T)            # the reference carries [C, F]
+    labels = g["labels"]
+    if labels.shape[0] != feats.shape[0]:
+        labels = labels[:-1]
+    for framenum in (11, 17):
+        for randomint, tag in ((-11, "m11"), (3, "3")):
+            order = None if randomint == -11 else O.random_order(randomint, feats.shape[0])
+            tiles = O.stack_context_tiles(feats, framenum, order)
+            ref = g[f"tiles_n{framenum}_r{tag}"]
+            assert tiles.dtype == np.float32 and np.array_equal(tiles, ref)
+            want_lab = labels if order is None else labels[order]
+            assert np.array_equal(want_lab, g[f"labels_n{framenum}_r{tag}"])
+            mb = g[f"minibatch_n{framenum}_r{tag}"]
+            assert mb.shape == (16, 39, framenum, 1) and np.array_equal(mb[..., 0], ref[:16].astype(np.float64))
+            # the two layouts hold the same windows
+            fm = O.stack_context(feats, framenum)
+            sel = fm if order is None else fm[order]
+            assert np.array_equal(sel.reshape(-1, framenum, 39).transpose(0, 2, 1), ref)
+
+
+GEOMS = ("8k", "44k", "16k_20ms", "16k_32ms_8ms")
+
+
+@pytest.mark.parametrize("gname", GEOMS)
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_other_frame_geometries(golden, gname, variant):
+    """winfft derives frame size, step and FFT length from (fs, frame_time, step_time)
+    (self5:75-84): 8 kHz -> 200/80/256, 44.1 kHz -> 1102/441/2048, 20 ms -> 320/160/512."""
+    g = golden("geometry.npz")
+    fs, frame_time, step_time = (float(v) for v in g[f"{gname}_cfg"])
+    size, step, nfft = O.frame_geometry(fs, frame_time, step_time)
+    assert nfft == int(g[f"{gname}_nfft"])
+    for length in g[f"{gname}_lengths"]:
+        audio = g[f"{gname}_audio_{length}"]
+        st = O.mfcc39(audio, variant, fs=fs, frame_time=frame_time, step_time=step_time, loop=False, return_stages=True)
+        assert st["out"].shape == (O.frame_count(length, size, step), 39)
+        close(st["out"], g[f"{gname}_{variant}_out_{length}"], 1e-10)
+        close(st["logmel"], g[f"{gname}_{variant}_logmel_{length}"], 1e-11)
+        close(st["loge"], g[f"{gname}_{variant}_loge_{length}"], 1e-12)
+        key = f"{gname}_{variant}_spec_{length}"
+        if key in g.files:
+            close(st["pow"] if variant == "self5" else st["mag"], g[key], 1e-12)
