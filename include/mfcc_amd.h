@@ -181,6 +181,15 @@ int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t fe
  * and keeps; ncol <= 1024. */
 int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums,
                          void* stream);
+/* No counterpart in the reference.  The same operation with the same results for callers that
+ * cannot allocate device memory at call time (code under HIP graph capture, serving loops,
+ * harnesses that forbid hipMalloc): the partial sums go to a fixed 4.3 MB device array that is
+ * part of the library image (one copy per GPU, held until the process ends), so the call never
+ * allocates.  ncol <= MFCC_CMVN_STATIC_MAX_COLS, otherwise MFCC_ERR_UNSUPPORTED.  All calls on one
+ * GPU share that array: calls that overlap in time on one GPU (different streams) race. */
+#define MFCC_CMVN_STATIC_MAX_COLS 264
+int mfcc_cmvn_accumulate_static(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums,
+                                void* stream);
 /* feats[r,c] = (feats[r,c] + mm[c]) * vv[c] in place; mm, vv are float32[ncol] on the device */
 int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, const float* mm, const float* vv,
                     void* stream);

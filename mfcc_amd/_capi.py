@@ -19,6 +19,7 @@ SPECTRUM_POWER, SPECTRUM_MAG = 0, 1
 WINDOW_NONE, WINDOW_HAMMING = 0, 1
 OUT_MFCC39, OUT_STATIC, OUT_LOGMEL, OUT_SPEC, OUT_LOGSPEC = 0, 1, 2, 3, 4
 STACK_FRAME_MAJOR, STACK_TILE = 0, 1
+CMVN_STATIC_MAX_COLS = 264
 
 
 class MfccConfig(C.Structure):
@@ -79,6 +80,7 @@ SIGNATURES = {
     "mfcc_copy_cols": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "mfcc_stack_context": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mfcc_cmvn_accumulate": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    "mfcc_cmvn_accumulate_static": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "mfcc_cmvn_apply": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "mfcc_utt_scalar_norm": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "mfcc_pad_batch": (C.c_int, [_vp, _vp, _i64, _i32, _i32, C.c_float, _i32, _i32, _vp, _vp]),

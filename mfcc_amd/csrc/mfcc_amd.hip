@@ -83,6 +83,33 @@ int cmvn_workspace(hipStream_t stream, size_t bytes, double** out) {
   return MFCC_OK;
 }
 
+// Scratch of mfcc_cmvn_accumulate_static: the same partial sums in a device array that is part of
+// the code object, so the entry point never allocates.  One copy per GPU, shared by every call on
+// that GPU, held until the process ends.
+constexpr int kCmvnStaticCols = MFCC_CMVN_STATIC_MAX_COLS;  // >= 257 spectrum bins
+constexpr size_t kCmvnStaticDoubles = (size_t)mfcc::kCmvnMaxBlocks * 2 * kCmvnStaticCols;
+static __device__ __align__(256) double g_cmvn_scratch[kCmvnStaticDoubles];  // 4.3 MB
+constexpr int kMaxDevices = 64;
+double* g_cmvn_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+// Device address of g_cmvn_scratch on the current device (resolved once per device: the array's
+// name is only a host-side handle, each GPU holds its own copy at its own address).
+int cmvn_static_scratch(double** out) {
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  if (device < 0 || device >= kMaxDevices) return fail(MFCC_ERR_UNSUPPORTED, "device index %d outside 0..%d", device, kMaxDevices - 1);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_cmvn_scratch_ptr[device]) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_cmvn_scratch)));
+    if (!p) return fail(MFCC_ERR_HIP, "hipGetSymbolAddress returned a null address for the CMVN scratch");
+    g_cmvn_scratch_ptr[device] = (double*)p;
+  }
+  *out = g_cmvn_scratch_ptr[device];
+  return MFCC_OK;
+}
+
 // Both stages of the CMVN reduction on `st`, partial sums in `partial` (>= nblk*2*ncol doubles).
 int launch_cmvn(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums, double* partial, int nblk,
                 int64_t rows_per_block, hipStream_t st) {
@@ -262,6 +289,13 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   if (cfg->low_freq < 0 || cfg->low_freq >= cfg->fs / 2) return fail(MFCC_ERR_INVALID, "low_freq=%g", cfg->low_freq);
 
   HIP_TRY(hipSetDevice(device));
+  {
+    // set-up time is where the static scratch of mfcc_cmvn_accumulate_static gets its address
+    // on this device (that entry point resolves it itself if no plan was ever created here)
+    double* scratch = nullptr;
+    const int rc_s = cmvn_static_scratch(&scratch);
+    if (rc_s) return rc_s;
+  }
   mfcc_plan* p = new (std::nothrow) mfcc_plan();
   if (!p) return fail(MFCC_ERR_NOMEM, "mfcc_plan_create: out of host memory");
   p->cfg = *cfg;
@@ -723,6 +757,24 @@ int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, i
   double* partial = nullptr;
   const int rc = cmvn_workspace((hipStream_t)stream, (size_t)mfcc::kCmvnMaxBlocks * 2 * ncol * sizeof(double), &partial);
   if (rc) return rc;
+  return launch_cmvn(feats, feats_ld, n_rows, ncol, sums, partial, nblk, rpb, (hipStream_t)stream);
+}
+
+int mfcc_cmvn_accumulate_static(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums, void* stream) {
+  if (n_rows < 0 || ncol < 1 || feats_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate_static: bad shape");
+  if (ncol > kCmvnStaticCols)
+    return fail(MFCC_ERR_UNSUPPORTED, "mfcc_cmvn_accumulate_static: %d columns, the static scratch holds at most %d "
+                "(use mfcc_cmvn_accumulate)", ncol, kCmvnStaticCols);
+  if (n_rows == 0) return MFCC_OK;
+  if (!feats || !sums) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate_static: null pointer");
+  int nblk;
+  int64_t rpb;
+  cmvn_split(n_rows, &nblk, &rpb);
+  double* partial = nullptr;
+  const int rc = cmvn_static_scratch(&partial);
+  if (rc) return rc;
+  // every partial the second stage reads is written by the first stage of this very call, so
+  // nothing of an earlier call's contents has to be cleared
   return launch_cmvn(feats, feats_ld, n_rows, ncol, sums, partial, nblk, rpb, (hipStream_t)stream);
 }
 

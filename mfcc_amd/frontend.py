@@ -450,10 +450,11 @@ class StreamingMFCC:
 # --------------------------------------------------------------------------
 # CMVN
 # --------------------------------------------------------------------------
-def cmvn_accumulate(feats, sums=None):
+def cmvn_accumulate(feats, sums=None, static=False):
     """Adds (n, sum x, sum x^2) of the rows of ``feats`` into the float64 device vector
     ``sums`` of length 1 + 2*D (allocated and zeroed when None).  The reduction order is fixed,
-    so equal inputs give bit-identical sums."""
+    so equal inputs give bit-identical sums.  ``static=True`` uses the entry point that keeps
+    its partial sums in a fixed device array of the library (D <= 264) and never allocates."""
     if not feats.is_cuda or feats.dtype != torch.float32 or feats.dim() != 2 or feats.stride(1) != 1:
         raise ValueError("feats must be a float32 device tensor [rows, D] with unit column stride")
     n, d = feats.shape
@@ -462,7 +463,7 @@ def cmvn_accumulate(feats, sums=None):
     elif sums.dtype != torch.float64 or sums.numel() != 1 + 2 * d or not sums.is_contiguous():
         raise ValueError("sums must be a contiguous float64 vector of 1 + 2*D elements")
     lib = capi.load()
-    fn = lib.mfcc_cmvn_accumulate
+    fn = lib.mfcc_cmvn_accumulate_static if static else lib.mfcc_cmvn_accumulate
     with _on(feats.device, sums):
         capi.check(fn(_ptr(feats), feats.stride(0), n, d, _ptr(sums), _stream_ptr()))
     return sums
