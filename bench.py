@@ -2,6 +2,7 @@
 """Headline benchmark: MFCC-39 frames/s on synthetic 16 kHz audio (BASELINE.json configs[1]).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --config D [--gpus N] [--hours H]      corpus + CMVN pipeline (BASELINE.json configs[3])
 
 One "step" is one pass of the fused hot path (mfcc_forward, MFCC-39 output) over a batch of
 10 000 three-second int16 utterances that is already resident in HBM; the [2 990 000, 39]
@@ -65,21 +66,177 @@ def cpu_baseline():
         wall = time.perf_counter() - t0
     frames = sum(r[0] for r in res)
     return {
-        "value": round(frames / wall, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+        "value": round(frames / wall, 1), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
         "sample": f"{cores * per_worker} synthetic 3 s utterances ({frames} frames) over {cores} processes, "
                   f"loop-faithful float64 numpy restatement of mfcc-self5.py",
         "value_1core": round(f1 / t1, 1), "sample_1core": f"{n1} utterances ({f1} frames), 1 process",
     }
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def kernel_revision():
+    """Identifies the kernel sources a measurement belongs to: sha1 over mfcc_amd/csrc/*."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(ROOT, "mfcc_amd", "csrc", "*"))):
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def synth_audio(n_utt, dev, gen, torch):
+    audio = torch.empty((n_utt, UTT_LEN), dtype=torch.int16, device=dev)
+    for i in range(0, n_utt, 1000):   # generate in chunks: the float32 noise is 4x the int16 batch
+        m = min(1000, n_utt - i)
+        audio[i:i + m] = (torch.randn(m, UTT_LEN, generator=gen, device=dev) * 3000).clamp(-32768, 32767).to(torch.int16)
+    return audio
+
+
+def extra_measurements(torch, mfcc_amd, dev, audio, fe, layout):
+    """Compact figures for the other BASELINE configurations, carried in the same JSON line:
+    C = 257-bin ln power spectrum with 17-frame context stacking of the same 10 000 utterances,
+    E = host-observed latency of one 10 ms hop of B lock-step live streams."""
+    import numpy as np
+    extra = {}
+    frames = layout.total_frames
+    try:
+        ctx = torch.empty((frames, 17 * 257), dtype=torch.float32, device=dev)
+        flat = audio.view(-1)
+
+        def run_c():
+            mfcc_amd.spectrum_stack(fe, flat, layout, 17, out=ctx)
+        for _ in range(2):
+            run_c()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in ev:
+            a.record()
+            run_c()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)[2]
+        alg = 2 * N_UTT * UTT_LEN + 4 * 257 * 17 * frames
+        extra["C"] = {"workload": "10000 x 3 s -> ln |X|^2/512 [frames, 257] -> 17-frame stack [frames, 4369] (BASELINE.json configs[2])",
+                      "ms": round(ms, 3), "frames_per_s": round(frames / (ms * 1e-3), 1), "algorithmic_bytes": alg,
+                      "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del ctx
+        torch.cuda.empty_cache()
+    except Exception as exc:   # a secondary figure must not take the headline down
+        extra["C"] = {"error": repr(exc)[:200]}
+    try:
+        e = {}
+        for B in (1, 64):
+            s = mfcc_amd.StreamingMFCC("self5", n_streams=B, max_chunk=160, device=dev)
+            hops = 520
+            chunk = (torch.randn(B, 160 * hops, device=dev) * 3000).clamp(-32768, 32767).to(torch.int16)
+            out = torch.empty((B, s.max_rows, 39), dtype=torch.float32, device=dev)
+            lat = []
+            for h in range(hops):
+                t0 = time.perf_counter()
+                s.push(chunk[:, h * 160:(h + 1) * 160], out=out)
+                torch.cuda.synchronize()
+                if h >= 20:
+                    lat.append((time.perf_counter() - t0) * 1e6)
+            lat.sort()
+            e[f"B{B}"] = {"us_per_hop_p50": round(lat[len(lat) // 2], 1), "us_per_hop_p99": round(lat[int(len(lat) * 0.99)], 1)}
+        e["workload"] = "10 ms hops of B lock-step int16 streams, push + host wait per hop (BASELINE.json configs[4])"
+        extra["E"] = e
+    except Exception as exc:
+        extra["E"] = {"error": repr(exc)[:200]}
+    return extra
+
+
+def run_config_d(args, rank, world, dev, torch, mfcc_amd, dist):
+    """BASELINE.json configs[3]: hours of synthetic audio utterance-sharded over the GPUs, MFCC-39 kept in
+    HBM, corpus-wide CMVN (float64 sums, one all-gather of 79 doubles over RCCL), rows normalised in place."""
+    import numpy as np
+    n_total = int(round(args.hours * 3600 / 3.0))                       # three-second utterances in the corpus
+    lengths_all = np.full(n_total, UTT_LEN, dtype=np.int64)
+    fe = mfcc_amd.MFCC(args.variant, device=dev)
+    begin, end = mfcc_amd.shard_utterances(lengths_all, world, fe.plan)[rank]
+    n_local = end - begin
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    audio = synth_audio(n_local, dev, gen, torch).view(-1)
+    lengths = lengths_all[begin:end]
+    frames_local = n_local * FRAMES_PER_UTT
+    out = torch.empty((frames_local, 39), dtype=torch.float32, device=dev)
+    # warm-up on the first chunk: loads every kernel and the collective
+    for _ in range(max(1, args.warmup)):
+        mfcc_amd.corpus_mfcc_cmvn(fe, audio[:min(n_local, 2000) * UTT_LEN], lengths[:2000], out=out[:min(n_local, 2000) * FRAMES_PER_UTT])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    phase_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        events = {}
+        feats, sums, mm, vv = mfcc_amd.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=out, events=events)
+        torch.cuda.synchronize()
+        for k, evs in events.items():
+            phase_ms[k] = phase_ms.get(k, 0.0) + sum(a.elapsed_time(b) for a, b in evs)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_in_sums = int(sums[0].item())
+    mean_abs = float(feats[:: 997].double().mean(0).abs().max().item())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert n_in_sums == n_total * FRAMES_PER_UTT, (n_in_sums, n_total * FRAMES_PER_UTT)
+    if rank == 0:
+        total_frames = n_total * FRAMES_PER_UTT
+        value = total_frames * args.steps / elapsed
+        alg_rank = 2 * n_local * UTT_LEN + 468 * frames_local            # pass 1: 2 B/sample + 156 B/frame; pass 2: 2 x 156 B/frame
+        step_s = elapsed / args.steps
+        rec = {
+            "metric": "MFCC-39 + corpus CMVN frames/sec (whole node)", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.hours:g} h of synthetic 16 kHz int16 audio ({n_total} x 3 s) utterance-sharded over {world} GPU(s) "
+                                   f"-> MFCC-39 resident in HBM -> corpus CMVN (BASELINE.json configs[3]), variant {args.variant}",
+                       "utterances_rank0": n_local, "frames_total": total_frames,
+                       "parallelism": f"utterance-sharded x{world}; one all-gather of 79 float64 per rank (RCCL), summed in rank order"},
+            "audio_hours_per_s": round(value / 360000.0, 2), "x_realtime": round(value / 100.0, 1),
+            "phases_ms_rank0_per_step": {k: round(v / args.steps, 3) for k, v in phase_ms.items()},
+            "roofline": {"bound": "hbm", "achieved": round(alg_rank / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_rank / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_step_rank0": alg_rank,
+                         "note": "two passes over the features: 2 B/sample + 156 B/frame written, then 156 B/frame read and written"},
+            "checks": {"frames_in_sums": n_in_sums, "normalised_mean_abs_max_sampled": mean_abs},
+        }
+        print(json.dumps(rec), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--variant", default="self5", choices=("self5", "self15"))
+    ap.add_argument("--config", default="B", choices=("B", "D"),
+                    help="B: 10 000 x 3 s -> MFCC-39 per GPU (headline); D: --hours of audio sharded over the GPUs + corpus CMVN")
+    ap.add_argument("--hours", type=float, default=None, help="config D: corpus size in hours (default 125 per GPU: 1000 h on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the compact config C / E figures")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 50 if args.config == "B" else 3
+    if args.warmup is None:
+        args.warmup = 5 if args.config == "B" else 1
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started by hand without a launcher: start one process per GPU and relay the result
@@ -92,7 +249,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config == "B":
         cpu = cpu_baseline()          # before the GPU is touched: the pool must not inherit a HIP context
 
     import torch
@@ -100,14 +257,21 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.config == "D":
+        if args.hours is None:
+            args.hours = 125.0 * world
+        run_config_d(args, rank, world, dev, torch, mfcc_amd, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    audio = torch.empty((N_UTT, UTT_LEN), dtype=torch.int16, device=dev)
-    for i in range(0, N_UTT, 1000):   # generate in chunks: the float32 noise is 4x the int16 batch
-        audio[i:i + 1000] = (torch.randn(1000, UTT_LEN, generator=gen, device=dev) * 3000).clamp(-32768, 32767).to(torch.int16)
+    audio = synth_audio(N_UTT, dev, gen, torch)
     fe = mfcc_amd.MFCC(args.variant, device=dev)
     layout = fe.layout([UTT_LEN] * N_UTT)
     frames = layout.total_frames
@@ -142,24 +306,38 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the one collective of the front-end, outside the timed region: corpus CMVN sums
+        # the one exchange of the front-end, outside the timed region: corpus CMVN sums
         sums = mfcc_amd.cmvn_allreduce(mfcc_amd.cmvn_accumulate(out))
         assert int(sums[0].item()) == frames * world
 
     assert torch.isfinite(out[:: 9973]).all()
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        del out
+        torch.cuda.empty_cache()
+        extra = extra_measurements(torch, mfcc_amd, dev, audio, fe, layout)
     if rank == 0:
         total_frames = frames * world
         value = total_frames * args.steps / elapsed
         bytes_per_launch = 2 * N_UTT * UTT_LEN + 4 * 39 * frames          # int16 in + fp32 out
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = traffic_bytes = None
-        tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+        traffic = traffic_bytes = traffic_source = None
+        rev = kernel_revision()
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and args.variant == "self5":
             # HBM bytes per launch of this very workload, from separate rocprofv3 --pmc passes
-            # (FETCH_SIZE doubled as gfx950 requires, + WRITE_SIZE); counters cannot run inside this process
+            # (FETCH_SIZE doubled as gfx950 requires, + WRITE_SIZE); counters cannot run inside this
+            # process.  Used only while the file belongs to the kernel sources that are running.
             with open(tpath) as fh:
-                traffic_bytes = json.load(fh)["hbm_bytes_per_launch"]
-            traffic = round(traffic_bytes / (kernel_ms * 1e-3) / 1e9, 1)
+                tj = json.load(fh)
+            if tj.get("kernel_revision") == rev:
+                traffic_bytes = tj["hbm_bytes_per_launch"]
+                traffic = round(traffic_bytes / (kernel_ms * 1e-3) / 1e9, 1)
+                traffic_source = f"profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, kernel sources {rev})"
+            else:
+                traffic_source = f"none: profiles/hbm_traffic.json was measured on kernel sources {tj.get('kernel_revision')}, running {rev}"
+        flops_per_frame = 10600.0   # split-radix real FFT-512 7.7 k + |X|^2 0.8 k + sparse mel 0.9 k + DCT 0.7 k + ln, delta 0.5 k
+        fp32_tflops = flops_per_frame * frames / (kernel_ms * 1e-3) / 1e12
         rec = {
             "metric": "MFCC-39 frames/sec (whole node)",
             "value": round(value, 1),
@@ -188,11 +366,19 @@ def main():
                 "kernel": "mfcc::fused_kernel<0, 13, short, mfcc::FrameGeom<400, 160>>", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "traffic_bytes_per_launch": traffic_bytes,
-                "traffic_source": "profiles/r1_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic_source": traffic_source,
+                "kernel_revision": rev,
+            },
+            "roofline_fp32": {
+                "bound": "valu", "achieved": round(fp32_tflops, 2), "peak": 157.3, "unit": "TFLOP/s",
+                "frac": round(fp32_tflops / 157.3, 4), "flops_per_frame": flops_per_frame,
+                "note": "minimum-work count (split-radix real FFT, sparse filterbank); secondary line, the HBM roofline is the headline",
             },
         }
         if cpu is not None:
             rec["cpu_baseline"] = cpu
+        if extra is not None:
+            rec["extra"] = extra
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -317,6 +317,15 @@ def spectrum257(audio, lengths=None, preemph=0.97, spectrum="power", window=None
                   kind="logspec" if log else "spec")
 
 
+def spectrum_stack(fe, audio, layout, framenum, out=None, log=True, spec=None):
+    """The "257 coefficients x N frames" input of the MLP/CNN scripts (MLP_5hidlayer_40.py:244-248)
+    straight from audio: spectrum rows of ``fe`` (ln of them when ``log``) stacked over ``framenum``
+    frames with edge replication per utterance -> float32 [sum F, framenum * (nfft/2+1)]."""
+    kind = "logspec" if log else "spec"
+    spec = fe.forward(audio, layout, out=spec, kind=kind)
+    return stack_context(spec, framenum, frame_counts=np.diff(layout.frame_offsets), out=out)
+
+
 _frame_layouts = {}
 
 
@@ -476,8 +485,10 @@ def cmvn_allreduce(sums, group=None):
     order of the additions to the collective's algorithm.  A no-op without a process group."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        parts = [torch.empty_like(sums) for _ in range(dist.get_world_size(group))]
-        dist.all_gather(parts, sums.contiguous(), group=group)
+        # a host-side backend (gloo) gathers host copies; RCCL gathers the device vectors directly
+        buf = sums.contiguous() if dist.get_backend(group) == "nccl" or not sums.is_cuda else sums.cpu()
+        parts = [torch.empty_like(buf) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, buf, group=group)
         total = parts[0].clone()
         for p in parts[1:]:
             total += p
