@@ -77,19 +77,33 @@ __device__ __forceinline__ cf mul_mi(cf a) {
   asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(a));
   return d;
 }
-// a * w, w in vector registers (lane-dependent twiddle)
+// a * w, w in vector registers (lane-dependent twiddle).  Both instructions sit in one asm
+// statement: the compiler assumes that an asm statement's result may need a wait state before
+// its first use and pads with s_nop when the use comes next; inside the statement the hardware's
+// own interlock orders the two.
 __device__ __forceinline__ cf cmul(cf a, cf w) {
   cf t, d;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=v"(d), "=&v"(t) : "v"(a), "v"(w));
   return d;
 }
 // a * w, w wave-uniform (scalar register pair)
 __device__ __forceinline__ cf cmulk(cf a, cf w) {
   cf t, d;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=v"(d), "=&v"(t) : "v"(a), "s"(w));
   return d;
+}
+// two products at once, interleaved so that no instruction uses the result of the one before it
+__device__ __forceinline__ void cmul2(cf& a0, cf w0, cf& a1, cf w1) {
+  cf t0, t1;
+  asm("v_pk_mul_f32 %2, %0, %4 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %3, %1, %5 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %0, %4, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %1, %1, %5, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "+v"(a0), "+v"(a1), "=&v"(t0), "=&v"(t1) : "v"(w0), "v"(w1));
 }
 // (a.x + b.y, a.x - b.y) and (a.y - b.x, a.y + b.x): the x parts, resp. y parts, of a - i b and a + i b
 __device__ __forceinline__ cf pair_x(cf a, cf b) {
@@ -115,6 +129,7 @@ MFCC_HD cf sub_conj(cf a, cf b) { return mk(a.x - b.x, a.y + b.y); }
 MFCC_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }
 MFCC_HD cf cmul(cf a, cf w) { return mk(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
 MFCC_HD cf cmulk(cf a, cf w) { return cmul(a, w); }
+MFCC_HD void cmul2(cf& a0, cf w0, cf& a1, cf w1) { a0 = cmul(a0, w0); a1 = cmul(a1, w1); }
 MFCC_HD cf pair_x(cf a, cf b) { return mk(a.x + b.y, a.x - b.y); }
 MFCC_HD cf pair_y(cf a, cf b) { return mk(a.y - b.x, a.y + b.x); }
 MFCC_HD float norm2(cf a) { return a.x * a.x + a.y * a.y; }
@@ -137,6 +152,35 @@ MFCC_HD void radix4(cf& a0, cf& a1, cf& a2, cf& a3) {
 MFCC_HD void fft16_a(cf (&x)[16]) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) radix4(x[b], x[4 + b], x[8 + b], x[12 + b]);
+}
+// First pass for a frame whose inputs x[NZ..15] are zero (a frame of frame_size real samples
+// fills complex points 0 .. frame_size/2 - 1, i.e. registers n1 < ceil(frame_size / 32)): the
+// butterflies lose the additions whose operand is a known zero.
+template <int NZ>
+MFCC_HD void fft16_a_pruned(cf (&x)[16]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    cf &a0 = x[b], &a1 = x[4 + b], &a2 = x[8 + b], &a3 = x[12 + b];
+    if (12 + b < NZ) {
+      radix4(a0, a1, a2, a3);
+    } else if (8 + b < NZ) {        // a3 = 0
+      const cf t0 = a0 + a2, t1 = a0 - a2, u = a1;
+      a0 = t0 + u;
+      a2 = t0 - u;
+      a1 = add_mi(t1, u);
+      a3 = sub_mi(t1, u);
+    } else if (4 + b < NZ) {        // a2 = a3 = 0
+      const cf t = a0, u = a1;
+      a0 = t + u;
+      a2 = t - u;
+      a1 = add_mi(t, u);
+      a3 = sub_mi(t, u);
+    } else {                        // only a0
+      a1 = a0;
+      a2 = a0;
+      a3 = a0;
+    }
+  }
 }
 MFCC_HD void fft16_b(cf (&x)[16]) {
   // after the first pass x[4c + b] holds Y_b[c]; twiddle by W16^(bc), W16^m = (cos, -sin)(2 pi m / 16)
@@ -165,6 +209,12 @@ MFCC_HD void fft16_c(cf (&x)[16]) {
 }
 MFCC_HD void fft16(cf (&x)[16]) {
   fft16_a(x);
+  fft16_b(x);
+  fft16_c(x);
+}
+template <int NZ>
+MFCC_HD void fft16_pruned(cf (&x)[16]) {
+  fft16_a_pruned<NZ>(x);
   fft16_b(x);
   fft16_c(x);
 }

@@ -61,25 +61,38 @@ constexpr int kMelSteps = 24;     // MFMA k-steps (4 bins each) every wave runs
 constexpr int kDctSteps = (kMaxMel + 3) / 4;
 
 // LDS carve (floats).
-constexpr int kSlot = 514;                           // LDS floats per frame slot (exchange buffer 512 + skew room)
-// Spectrum row of frame slot r starts at r*512 + row_skew(r) floats.  The skew is a bank offset
-// that serves both access patterns of the rows without conflicts: the untangle writes 16
-// consecutive columns from each of a wave's 4 frames (offsets 0,16,8,24 of rows 4w..4w+3 tile the
-// 32 banks exactly twice), the filterbank reads 4 consecutive columns of all 16 rows (16 distinct
-// even offsets).
-__host__ __device__ constexpr int row_skew(int r) { return 2 * (r >> 2) + 8 * ((r >> 1) & 1) + 16 * (r & 1); }
+constexpr int kSlot = 512;                           // LDS floats per frame slot: the 2 KiB exchange buffer of a frame
+// Spectrum row of frame slot r starts at r*512 + row_skew(r) floats.  The skew (a multiple of 4
+// floats, so rows stay 16-byte aligned) serves both access patterns of the rows without bank
+// conflicts: the untangle writes 16 consecutive columns from each of a wave's 4 frames with
+// ds_write_b32 (rows 4w and 4w+1, resp. 4w+2 and 4w+3, share an instruction half: their skews
+// differ by 16 banks), the filterbank reads 16 bytes per lane with ds_read_b128, whose 16-lane
+// groups hold rows {0-3, 12-15} at one column block and rows {4-11} at the next: both row sets
+// map onto the 8 even 16-byte slots.
+__host__ __device__ constexpr int row_skew(int r) { return 32 * ((r >> 3) & 1) + 16 * (r & 1) + 8 * ((r >> 1) & 1); }
 constexpr int kRowPad = 260;                         // bins 0..256 plus zeros up to a multiple of 4
 constexpr int kXbufFloats = kBatch * kSlot;          // exchange buffers (fb*512) / spectrum rows; epilogue scratch
 constexpr int kAbufFloats = 2808;                    // staged audio: kStage + up to 7 alignment samples, whole chunks
-constexpr int kLogPitch = 49;                        // ln-mel row of a frame (odd pitch: conflict-free column reads)
-constexpr int kLbufFloats = kBatch * kLogPitch;
+constexpr int kLogPitch = 41;                        // ln-mel row of a frame: kMaxMel columns, odd pitch (conflict-free column reads)
+constexpr int kLbufFloats = 4 * kBatch * 20;         // four partial-DCT tiles (one per wave), see kPartPitch
 constexpr int kEpFloats = 4 * kBatch;                // energy partial of wave w for frame f at [w*16 + f]
 constexpr int kHbufFloats = 2 * kHalo * kMaxCep;     // static features of the halo frames
-constexpr int kDctBFloats = kDctSteps * 64;          // B operands of the DCT product, shared by the 4 waves
-constexpr int kTwPitch = 46;                         // per-lane-index twiddle row: 15 + 8 complex values
+constexpr int kDctBFloats = 0;                       // the DCT weights of a wave stay in its registers
+constexpr int kPartPitch = 20;                       // partial-DCT row of a frame: 16 coefficients, padded so that
+constexpr int kPartTile = kBatch * kPartPitch;       //   the 16-byte column-block writes of 8 lanes tile the banks
+// per-lane-index twiddle row: 8 untangle values, then 15 stage-1 values, read 16 bytes at a time;
+// 52 q mod 64 are 16 distinct multiples of 4, so the 16 rows a read touches cover all 64 banks
+constexpr int kTwPitch = 52;
+constexpr int kTwUnt = 0, kTwSt1 = 8;                // complex index of the first untangle / stage-1 value
 constexpr int kTwFloats = 16 * kTwPitch;             // rows for q = 0..15 (46 q mod 64 are distinct even banks)
 constexpr int kSmemFloats =
     kXbufFloats + kAbufFloats + kLbufFloats + kEpFloats + kHbufFloats + kDctBFloats + kTwFloats;
+// gfx950 hands out LDS in units of 1280 bytes; three workgroups per CU fit while each takes at
+// most 42 units of the CU's 128
+static_assert(kSmemFloats * 4 <= 42 * 1280, "LDS carve no longer allows three workgroups per CU");
+static_assert(kLogPitch > kMaxMel && kLogPitch % 2 == 1, "ln-mel row pitch");
+static_assert(kMelCols == 15, "filter slot 15 of a wave carries its energy partial");
+static_assert((kBatch - 1) * 512 + row_skew(kBatch - 1) + kRowPad <= kXbufFloats, "spectrum rows fit in the exchange buffer");
 
 constexpr float kEps64 = 2.220446049250313e-16f;     // np.finfo(float).eps, mfcc-self5.py:131
 
@@ -114,6 +127,8 @@ struct PlanConst {
   const float* tw512;     // [512][2]  exp(-2 pi i m / 512)
   const float* melB;      // [4][kMelSteps/4][64][4] B operands (filter weights * spec_scale): 16 B per lane and 4 k-steps
   const float* dctB;      // [kDctSteps/2][64][2] B operands of the DCT*lifter product: 8 B per lane and 2 k-steps
+  const float* dctA;      // [4 waves][64][4] per-wave DCT*lifter weights of the chained product: lane (c = lane & 15,
+                          //   g = lane >> 4), element r = weight of (filter first_filter[w] + 4 g + r, coefficient c)
   const float* window;    // [512] or nullptr
   MelMap map;
   int32_t mel_steps[4];   // k-steps wave w really needs (<= kMelSteps)
@@ -169,6 +184,11 @@ __device__ __forceinline__ void wave_sync() {
 // ln x from the hardware log2 (v_log_f32, 1 ulp): relative error ~2e-7 for the mel energies
 // (x >> denormal range); ln 0 = -inf as numpy's.
 __device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+
+// 32-bit LDS address of a pointer into the workgroup's shared memory (for hand-written DS instructions)
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
 
 __device__ __forceinline__ float lane_read(int byte_addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
@@ -352,7 +372,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     for (int i = tid; i < 16 * 23; i += 256) {
       const int qq = i / 23, k = i - qq * 23;
       const int m = k < 15 ? (2 * qq * (k + 1)) & 511 : qq + 16 * (k - 15);
-      *(cf*)(twl + qq * kTwPitch + 2 * k) = mk(tw[2 * m], tw[2 * m + 1]);
+      const int slot = k < 15 ? kTwSt1 + k : kTwUnt + (k - 15);
+      *(cf*)(twl + qq * kTwPitch + 2 * slot) = mk(tw[2 * m], tw[2 * m + 1]);
     }
   }
   const cf* const twq = (const cf*)(twl + q * kTwPitch);
@@ -366,15 +387,16 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     return sr.delta;
   };
   // floor of the mel energies: 0 = none (ln 0 = -inf as the reference, mfcc-self5.py:125-127)
-  const float mel_floor = pc->floor_mel != 0 ? kEps64 : 0.f;
+  const bool floor_mel = pc->floor_mel != 0;
 
   stage_ld(s_lo);
-  // columns nmel.. of the ln-mel rows are multiplied by zero DCT weights: keep them finite
-  for (int i = tid; i < kLbufFloats; i += 256) lbuf[i] = 0.f;
+  // DCT*lifter weights of this wave's filter group (A operand of the chained product), 4 registers
+  f32x4 dw;
   {
-    const gfloat_ptr src = as_global(pc->dctB);
-    for (int i = tid; i < kDctBFloats; i += 256) dctb[i] = src[i];
+    typedef const f32x4 __attribute__((address_space(1))) * gf4;
+    dw = ((gf4)(uintptr_t)pc->dctA)[wave * 64 + lane];
   }
+  (void)dctb;
   int delta = stage_st(s_lo);
   __syncthreads();
 
@@ -403,17 +425,44 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         }
       } else {
         const cf* fa2 = (const cf*)__builtin_assume_aligned(fa, 8);
+        // Registers that lie wholly inside the frame are read with one ds_read_b64 each, written out
+        // by hand: the compiler pairs neighbouring 8-byte reads into ds_read2_b64, which occupies the
+        // LDS twice as long for the same bytes.  Issued in the order the first pass consumes them
+        // (x[b], x[4+b], x[8+b] for b = 0..3); LDS reads return in order, so a counted wait releases
+        // one butterfly's operands at a time.  The waits carry the registers as operands so that no
+        // use can be scheduled in front of them.
+        constexpr int kFull = (G::kSize / 2) / 16;  // registers n1 < kFull need no mask
+        const unsigned xa = lds_addr(fa2 + q);
+        int issued = 0;
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-          const int n = 16 * n1 + q;  // complex sample index: (x[2n], x[2n+1])
-          if (2 * (16 * n1 + 15) + 1 < G::kSize) {
-            x[n1] = fa2[n];
-          } else if (2 * (16 * n1) < G::kSize) {
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int n1 = 4 * a + b;
+            if (n1 < kFull) {
+              asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[n1]) : "v"(xa), "i"(n1 * 128));
+              ++issued;
+            }
+          }
+        (void)issued;
+#pragma unroll
+        for (int n1 = kFull; n1 < 16; ++n1) {
+          const int n = 16 * n1 + q;
+          if (2 * (16 * n1) < G::kSize) {
             const float ok = 2 * n + 1 < G::kSize ? 1.f : 0.f;  // staged samples are finite: 0 * v = 0
             x[n1] = fa2[min(n, G::kSize / 2 - 1)] * mk(ok, ok);
           } else {
             x[n1] = mk(0.f, 0.f);
           }
+        }
+        static_assert(kFull == 12 || kFull == 6, "wait counts below are written for 400- and 200-sample frames");
+        if (kFull == 12) {
+          asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(x[0]), "+v"(x[4]), "+v"(x[8]));
+          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x[1]), "+v"(x[5]), "+v"(x[9]));
+          asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(x[2]), "+v"(x[6]), "+v"(x[10]));
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[3]), "+v"(x[7]), "+v"(x[11]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
         }
       }
       if (window) {
@@ -426,11 +475,18 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       }
       // stage-1 twiddles of this lane: read now (their latency hides under the first 16-point
       // transform); reading them between the exchange writes would serialise on LDS round trips
-      cf tw1[15];
+      cf tw1[16];
+      {
+        const float4* const tv = (const float4*)__builtin_assume_aligned(twq + kTwSt1, 16);
 #pragma unroll
-      for (int k1 = 1; k1 < 16; ++k1) tw1[k1 - 1] = twq[k1 - 1];
+        for (int j = 0; j < 8; ++j) {
+          const float4 v = tv[j];  // the last half of the last read is padding
+          tw1[2 * j] = mk(v.x, v.y);
+          tw1[2 * j + 1] = mk(v.z, v.w);
+        }
+      }
 #ifndef MFCC_ABL_FFT
-      fft16(x);
+      fft16_pruned<(G::kSize + 31) / 32>(x);  // registers from ceil(size / 32) on hold zero padding
 #endif
       // Exchange buffer of this frame: 2 KiB at byte offset fb*2048 (the LDS carve starts at a
       // 128-byte boundary), element Y[k1][n2] at xpose_index(k1, n2)*8.  Written out in bytes so
@@ -484,8 +540,11 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         cf pb[4], pw[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) pb[s] = mk(lane_read(partner_addr, x[15 - h - s].x), lane_read(partner_addr, x[15 - h - s].y));
-#pragma unroll
-        for (int s = 0; s < 4; ++s) pw[s] = twq[15 + h + s];
+        {
+          const float4* const tv = (const float4*)__builtin_assume_aligned(twq + kTwUnt + h, 16);
+          const float4 v0 = tv[0], v1 = tv[1];
+          pw[0] = mk(v0.x, v0.y); pw[1] = mk(v0.z, v0.w); pw[2] = mk(v1.x, v1.y); pw[3] = mk(v1.z, v1.w);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           if (q == 0) pb[s] = x[(16 - h - s) & 15];  // lane 0 pairs inside itself: Z[16 s] with Z[16 (16 - s)]
@@ -549,7 +608,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #endif
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-      const float* Prow = xbuf + q * 512 + row_skew(q) + g4 + mel_k0;
+      // k-step s of lane group g4 takes bin mel_k0 + 16 (s / 4) + 4 g4 + (s % 4): four consecutive
+      // steps of a lane are 16 contiguous bytes (one ds_read_b128); the plan lays the weights out
+      // in the same order
+      const float* Prow = xbuf + q * 512 + row_skew(q) + 4 * g4 + mel_k0;
 #ifndef MFCC_ABL_MEL
       // All kMelSteps k-steps run unconditionally (no branch between them, so the operand reads
       // are issued ahead of the chain); steps a wave does not need carry zero weights, and the
@@ -557,32 +619,46 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // dependency chain is half as long.
       float pa[kMelSteps];
 #pragma unroll
-      for (int s = 0; s < kMelSteps; ++s) pa[s] = Prow[4 * s];
+      for (int s = 0; s < kMelSteps; s += 4) {
+        const float4 v = *(const float4*)__builtin_assume_aligned(Prow + 4 * s, 16);
+        pa[s] = v.x; pa[s + 1] = v.y; pa[s + 2] = v.z; pa[s + 3] = v.w;
+      }
+      // The product is formed transposed, D[filter slot][frame] (weights as the A operand): a lane
+      // then holds filter slots 4 g4 + r of frame q, which is exactly the B-operand layout of a
+      // following product that sums over the filter slots -- the DCT needs no trip through LDS.
 #pragma unroll
       for (int s = 0; s < kMelSteps; s += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], bv[s], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s + 1], bv[s + 1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], pa[s], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s + 1], pa[s + 1], acc2, 0, 0, 0);
       }
       acc += acc2;
 #else
-      acc[0] = Prow[0]; acc[1] = Prow[4]; acc[2] = bv[0]; acc[3] = bv[1];
+      acc[0] = Prow[0]; acc[1] = Prow[16]; acc[2] = bv[0]; acc[3] = bv[1];
 #endif
-      // lane holds rows 4*g4 + r of column q: filters take ln at once (mfcc-self5.py:125-127,
-      // unfloored by default: ln 0 = -inf), column 15 is this wave's share of the energy sum
-      if (q < mel_nf) {
+      // slots below mel_nf are this wave's filters: ln at once (mfcc-self5.py:125-127, unfloored by
+      // default: ln 0 = -inf); slot 15 is this wave's share of the frame's energy sum
+      float lm[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[r];
-          if (v == 0.f) v = mel_floor;
-#ifndef MFCC_ABL_LOG
-          lbuf[(4 * g4 + r) * kLogPitch + mel_ff + q] = fast_ln(v);
-#else
-          lbuf[(4 * g4 + r) * kLogPitch + mel_ff + q] = v;
-#endif
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[r];
+        if (floor_mel && v == 0.f) v = kEps64;  // wave-uniform flag: the unfloored default pays nothing
+        lm[r] = 4 * g4 + r < mel_nf ? fast_ln(v) : 0.f;
+      }
+      if (g4 == 3) epbuf[wave * kBatch + q] = acc[3];
+      if (OUT == kOutLogmel) {
+        const int t = tb + q;
+        if (t < s_hi) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * g4 + r < mel_nf) out_t0[(t - t0) * ld + mel_ff + 4 * g4 + r] = lm[r];
         }
-      } else if (q == 15) {
+      } else {
+        // this wave's share of the DCT-II * lifter product (mfcc-self5.py:136-156): coefficient rows
+        // 4 g4 + r of frame q, summed over the wave's filters; the four shares meet in LDS
+        f32x4 pd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) epbuf[wave * kBatch + 4 * g4 + r] = acc[r];
+        for (int r = 0; r < 4; ++r) pd = __builtin_amdgcn_mfma_f32_16x16x4f32(dw[r], lm[r], pd, 0, 0, 0);
+        *(f32x4*)__builtin_assume_aligned(lbuf + wave * kPartTile + q * kPartPitch + 4 * g4, 16) = pd;
       }
     }
     MFCC_STAMP(tb3);
@@ -594,51 +670,21 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     MFCC_STAMP(tb5);
 
     if (OUT == kOutLogmel) {
-      if (tid < kBatch) {
+      // the ln-mel columns went out from registers; the energy column needs the four partials
+      if (tid < kBatch && tb + tid < s_hi) {
         float e = (epbuf[tid] + epbuf[16 + tid]) + (epbuf[32 + tid] + epbuf[48 + tid]);
         if (e == 0.f) e = kEps64;
-        xbuf[tid] = fast_ln(e);  // the exchange buffer is free until the next FFT
+        out_t0[(tb - t0 + tid) * ld + nmel] = fast_ln(e);
       }
-      __syncthreads();
-      const int nvalid = min(kBatch, s_hi - tb);
-      const int w = nmel + 1;
-      for (int idx = tid; idx < nvalid * w; idx += 256) {
-        const int f = idx / w, j = idx - f * w;
-        out_t0[(tb - t0 + f) * ld + j] = j < nmel ? lbuf[f * kLogPitch + j] : xbuf[f];
-      }
-      __syncthreads();
-      continue;
+      continue;  // epbuf is rewritten only after the next spectrum barrier
     }
-
-    // ---- DCT-II * lifter on the matrix cores, c0 := ln E  (mfcc-self5.py:136-167) ----------
-    // Every wave forms the whole 16 x 16 product (7 MFMAs) and stores a quarter of it, so no
-    // wave waits for another.  lbuf/epbuf are rewritten only after the next spectrum barrier.
-#ifndef MFCC_ABL_DCT
     {
-      // All kDctSteps k-steps run (no branch between them, operands are read ahead of the
-      // chain): rows of dctb past the plan's nmel are zero and the ln-mel columns they meet are
-      // never written (zero).  Two accumulators halve the dependency chain.
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
-      const float* Lr = lbuf + q * kLogPitch + g4;
-      float la[kDctSteps], lb[kDctSteps];
-#pragma unroll
-      for (int s = 0; s < kDctSteps; ++s) {
-        la[s] = Lr[4 * s];
-        lb[s] = dctb[((s >> 1) * 64 + lane) * 2 + (s & 1)];  // pairs of k-steps are one 8-byte read
-      }
-#pragma unroll
-      for (int s = 0; s < kDctSteps; s += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[s], lb[s], acc, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(la[s + 1], lb[s + 1], accb, 0, 0, 0);
-      }
-      acc += accb;
-      static_assert(kDctSteps % 2 == 0, "DCT k-steps are issued in pairs");
-      // The four waves hold the same product: wave w stores row 4*g4 + w of every lane group
-      // (one store instruction with all four groups active).  c0 := ln E, floored at the
-      // float64 epsilon (mfcc-self5.py:130-132 and :164).
-      const int i = 4 * g4 + wave;
+      // ---- sum of the four DCT shares, c0 := ln E (floored at the float64 epsilon,
+      // mfcc-self5.py:130-132 and :164); wave w finishes frames 4 w .. 4 w + 3, lane = (frame, coefficient)
+      const int i = 4 * wave + g4;
       const int t = tb + i;
-      float v = wave == 0 ? acc[0] : wave == 1 ? acc[1] : wave == 2 ? acc[2] : acc[3];
+      const float* const pp = lbuf + i * kPartPitch + q;
+      float v = (pp[0] + pp[kPartTile]) + (pp[2 * kPartTile] + pp[3 * kPartTile]);
       float e = (epbuf[i] + epbuf[16 + i]) + (epbuf[32 + i] + epbuf[48 + i]);
       if (e == 0.f) e = kEps64;
       e = fast_ln(e);
@@ -648,7 +694,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         else if (t < s_hi) hbuf[(t < t0 ? t - s_lo : kHalo + t - (t0 + nt)) * kMaxCep + q] = v;
       }
     }
-#endif
 #ifdef MFCC_DIAG
     {
       MFCC_STAMP(tb6);

@@ -141,6 +141,7 @@ struct mfcc_plan {
   mfcc::PlanConst* pc = nullptr;
   float* melB = nullptr;
   float* dctB = nullptr;
+  float* dctA = nullptr;
   float* window = nullptr;
   float pre_hi, pre_lo, spec_scale;
 };
@@ -342,7 +343,8 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
         es[4] = mfcc::kNbin;
         int mx = 0, sum = 0, k0[4], st[4];
         for (int g = 0; g < 4; ++g) {
-          const int lo = std::min(es[g], fb[g]), hi = std::max(lb[g] + 1, es[g + 1]);
+          // a wave's bin range starts at a multiple of 4 (its spectrum reads are 16-byte aligned)
+          const int lo = std::min(es[g], fb[g]) & ~3, hi = std::max(lb[g] + 1, es[g + 1]);
           k0[g] = std::min(lo, hi);
           st[g] = hi > lo ? (hi - lo + 3) / 4 : 0;
           mx = std::max(mx, st[g]);
@@ -364,13 +366,15 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   std::vector<float> melB((size_t)4 * mfcc::kMelSteps * 64, 0.f);
   for (int g = 0; g < 4; ++g) {
     // every wave runs all kMelSteps k-steps: keep them inside the zero-padded spectrum row
-    pmap.kstart[g] = std::min(best_k0[g], mfcc::kRowPad - 4 * mfcc::kMelSteps);
+    pmap.kstart[g] = std::min(best_k0[g] & ~3, mfcc::kRowPad - 4 * mfcc::kMelSteps);
+    static_assert((mfcc::kRowPad - 4 * mfcc::kMelSteps) % 4 == 0, "clamped start stays 16-byte aligned");
     pmap.first_filter[g] = best_cut[g];
     pmap.nfilt[g] = best_cut[g + 1] - best_cut[g];
     pch.mel_steps[g] = best_steps[g];
     for (int sidx = 0; sidx < mfcc::kMelSteps; ++sidx)
       for (int lane = 0; lane < 64; ++lane) {
-        const int k = pmap.kstart[g] + 4 * sidx + (lane >> 4), j = lane & 15;
+        // k-step sidx of lane group (lane >> 4) takes bin kstart + 16 (sidx / 4) + 4 (lane >> 4) + sidx % 4
+        const int k = pmap.kstart[g] + 16 * (sidx / 4) + 4 * (lane >> 4) + sidx % 4, j = lane & 15;
         double w = 0.0;
         if (k < mfcc::kNbin) {
           if (j < pmap.nfilt[g]) w = bank[(size_t)(best_cut[g] + j) * mfcc::kNbin + k];
@@ -389,6 +393,15 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
       if (m < nmel && c < cfg->numcep)  // [step/2][lane][step%2]: two k-steps of a lane are 8 contiguous bytes
         dctB[((size_t)(sidx / 2) * 64 + lane) * 2 + sidx % 2] = (float)dl[(size_t)m * cfg->numcep + c];
     }
+  // per-wave weights of the chained product (see PlanConst::dctA)
+  std::vector<float> dctA((size_t)4 * 64 * 4, 0.f);
+  for (int g = 0; g < 4; ++g)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int r = 0; r < 4; ++r) {
+        const int c = lane & 15, j = 4 * (lane >> 4) + r;
+        if (j < pmap.nfilt[g] && c < cfg->numcep)
+          dctA[((size_t)g * 64 + lane) * 4 + r] = (float)dl[(size_t)(pmap.first_filter[g] + j) * cfg->numcep + c];
+      }
   std::vector<float> win;
   if (cfg->window == MFCC_WINDOW_HAMMING) {
     const std::vector<double> h = mfcc::hamming(size);
@@ -397,13 +410,14 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   }
   int rc;
   if ((rc = upload(mfcc::twiddle512(), &p->tw512)) ||
-      (rc = upload(melB, &p->melB)) || (rc = upload(dctB, &p->dctB)) || (rc = upload(win, &p->window))) {
+      (rc = upload(melB, &p->melB)) || (rc = upload(dctB, &p->dctB)) || (rc = upload(dctA, &p->dctA)) || (rc = upload(win, &p->window))) {
     mfcc_plan_destroy(p);
     return rc;
   }
   pch.tw512 = p->tw512;
   pch.melB = p->melB;
   pch.dctB = p->dctB;
+  pch.dctA = p->dctA;
   pch.window = p->window;
   pch.nmel = nmel;
   pch.numcep = cfg->numcep;
@@ -426,6 +440,7 @@ int mfcc_plan_destroy(mfcc_plan* p) {
   (void)hipFree(p->tw512);
   (void)hipFree(p->melB);
   (void)hipFree(p->dctB);
+  (void)hipFree(p->dctA);
   (void)hipFree(p->window);
   (void)hipFree(p->pc);
   delete p;
