@@ -58,7 +58,6 @@ constexpr int kMaxMel = 40;       // "26-40 Mel bins" (mfcc-self5.py:23); bounds
 constexpr int kStage = (kBatch - 1) * kFrameStep + kFrameSize;  // 2800 samples per batch
 constexpr int kMelCols = 15;      // filter columns per wave; column 15 carries the wave's energy partial
 constexpr int kMelSteps = 24;     // MFMA k-steps (4 bins each) every wave runs
-constexpr int kDctSteps = (kMaxMel + 3) / 4;
 
 // LDS carve (floats).
 constexpr int kSlot = 512;                           // LDS floats per frame slot: the 2 KiB exchange buffer of a frame
@@ -71,37 +70,38 @@ constexpr int kSlot = 512;                           // LDS floats per frame slo
 // map onto the 8 even 16-byte slots.
 __host__ __device__ constexpr int row_skew(int r) { return 32 * ((r >> 3) & 1) + 16 * (r & 1) + 8 * ((r >> 1) & 1); }
 constexpr int kRowPad = 260;                         // bins 0..256 plus zeros up to a multiple of 4
-constexpr int kXbufFloats = kBatch * kSlot;          // exchange buffers (fb*512) / spectrum rows; epilogue scratch
+constexpr int kXbufFloats = kBatch * kSlot;          // exchange buffers (fb*512) / spectrum rows
 constexpr int kAbufFloats = 2808;                    // staged audio: kStage + up to 7 alignment samples, whole chunks
-constexpr int kLogPitch = 41;                        // ln-mel row of a frame: kMaxMel columns, odd pitch (conflict-free column reads)
-constexpr int kLbufFloats = 4 * kBatch * 20;         // four partial-DCT tiles (one per wave), see kPartPitch
-constexpr int kEpFloats = 4 * kBatch;                // energy partial of wave w for frame f at [w*16 + f]
-constexpr int kHbufFloats = 2 * kHalo * kMaxCep;     // static features of the halo frames
-constexpr int kDctBFloats = 0;                       // the DCT weights of a wave stay in its registers
-constexpr int kPartPitch = 20;                       // partial-DCT row of a frame: 16 coefficients, padded so that
-constexpr int kPartTile = kBatch * kPartPitch;       //   the 16-byte column-block writes of 8 lanes tile the banks
+// Partial-DCT tile of a wave: element (frame f, coefficient c) at [(c / 4) * 17 + f] * 4 + c % 4, i.e. four
+// blocks (one per 4 coefficients) of 16 frame slots + 1 spare slot of 16 bytes.  A lane's four
+// coefficients are one ds_write_b128 and the 8 lanes of a write group are contiguous; the spare
+// slot of block b carries the wave's energy partials of frames 4b .. 4b+3.
+constexpr int kPartSlots = 17;
+constexpr int kPartTile = 4 * kPartSlots * 4;
+constexpr int kPartFloats = 4 * kPartTile;
+// Ring of static-feature rows for the delta / delta-delta regression: row t of the tile sits at
+// ring row (t - s_lo + 8) mod 32; ring rows 0..7 are mirrored at 32..39 so that the 9 rows
+// t-4 .. t+4 a lane reads are always consecutive.
+constexpr int kRingRows = 40;
 // per-lane-index twiddle row: 8 untangle values, then 15 stage-1 values, read 16 bytes at a time;
 // 52 q mod 64 are 16 distinct multiples of 4, so the 16 rows a read touches cover all 64 banks
 constexpr int kTwPitch = 52;
 constexpr int kTwUnt = 0, kTwSt1 = 8;                // complex index of the first untangle / stage-1 value
-constexpr int kTwFloats = 16 * kTwPitch;             // rows for q = 0..15 (46 q mod 64 are distinct even banks)
-constexpr int kSmemFloats =
-    kXbufFloats + kAbufFloats + kLbufFloats + kEpFloats + kHbufFloats + kDctBFloats + kTwFloats;
+constexpr int kTwFloats = 16 * kTwPitch;
+// ring_pitch = floats per ring row: numcep where it is a compile-time constant, else kMaxCep
+constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + kPartFloats + kRingRows * ring_pitch + kTwFloats; }
 // gfx950 hands out LDS in units of 1280 bytes; three workgroups per CU fit while each takes at
-// most 42 units of the CU's 128
-static_assert(kSmemFloats * 4 <= 42 * 1280, "LDS carve no longer allows three workgroups per CU");
-static_assert(kLogPitch > kMaxMel && kLogPitch % 2 == 1, "ln-mel row pitch");
+// most 42 units of the CU's 128.  The 13-coefficient kernels meet that exactly.
+static_assert(smem_floats(13) * 4 <= 42 * 1280, "LDS carve no longer allows three workgroups per CU");
 static_assert(kMelCols == 15, "filter slot 15 of a wave carries its energy partial");
 static_assert((kBatch - 1) * 512 + row_skew(kBatch - 1) + kRowPad <= kXbufFloats, "spectrum rows fit in the exchange buffer");
 
 constexpr float kEps64 = 2.220446049250313e-16f;     // np.finfo(float).eps, mfcc-self5.py:131
 
-// Output frames per tile such that the epilogue's two LDS arrays, (nt+8) and (nt+4) rows of
-// numcep floats, fit in the exchange buffer; a multiple of the batch size.
-inline int tile_frames_for(int numcep) {
-  const int nt = (kXbufFloats / numcep - 12) / 2;
-  return nt / kBatch * kBatch;
-}
+// Output frames per tile: 19 batches of 16.  A tile's cost outside its batches (set-up, the halo
+// frames of a neighbouring tile) is spread over that many frames; more would only coarsen the
+// load balance between workgroups.
+inline int tile_frames_for(int /*numcep*/) { return 19 * kBatch; }
 
 struct Tile {
   int32_t utt;  // utterance index
@@ -126,7 +126,6 @@ struct MelMap {
 struct PlanConst {
   const float* tw512;     // [512][2]  exp(-2 pi i m / 512)
   const float* melB;      // [4][kMelSteps/4][64][4] B operands (filter weights * spec_scale): 16 B per lane and 4 k-steps
-  const float* dctB;      // [kDctSteps/2][64][2] B operands of the DCT*lifter product: 8 B per lane and 2 k-steps
   const float* dctA;      // [4 waves][64][4] per-wave DCT*lifter weights of the chained product: lane (c = lane & 15,
                           //   g = lane >> 4), element r = weight of (filter first_filter[w] + 4 g + r, coefficient c)
   const float* window;    // [512] or nullptr
@@ -328,11 +327,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   extern __shared__ __attribute__((aligned(128))) float smem[];
   float* const xbuf = smem;
   float* const abuf = xbuf + kXbufFloats;
-  float* const lbuf = abuf + kAbufFloats;
-  float* const epbuf = lbuf + kLbufFloats;
-  float* const hbuf = epbuf + kEpFloats;
-  float* const dctb = hbuf + kHbufFloats;
-  float* const twl = dctb + kDctBFloats;
+  constexpr int RP = NCEP > 0 ? NCEP : kMaxCep;  // floats per row of the statics ring
+  float* const part = abuf + kAbufFloats;
+  float* const ring = part + kPartFloats;
+  float* const twl = ring + kRingRows * RP;
 
   constexpr bool kSpecOut = (OUT == kOutSpec || OUT == kOutLogspec);
   const int tid = threadIdx.x;
@@ -396,9 +394,56 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     typedef const f32x4 __attribute__((address_space(1))) * gf4;
     dw = ((gf4)(uintptr_t)pc->dctA)[wave * 64 + lane];
   }
-  (void)dctb;
   int delta = stage_st(s_lo);
   __syncthreads();
+
+  // ---- delta, delta-delta and the output rows (mfcc-self5.py:169-186) ------------------------
+  // (-2a - b + 0m + d + 2e) / 10; the zero-weight centre tap keeps NaN propagation identical to
+  // np.dot over the window
+  auto regress = [](float a, float b, float m, float d, float e) { return (2.f * (e - a) + (d - b) + 0.f * m) * 0.1f; };
+  // Rows r_first .. r_first + 15 (those inside the tile): wave w, lane group g4 take row
+  // r_first + 4 w + g4, lane q its coefficient q, and write c | delta | delta-delta of that row, so
+  // the three stores of a wave cover four whole consecutive output rows.  The statics of rows
+  // r-4 .. r+4 come from the ring: consecutive ring rows away from the utterance's ends, row
+  // indices clamped to the utterance near them (np.pad(mode='edge'), mfcc-self5.py:174).  The
+  // reference pads twice -- delta-delta is the regression over the edge-padded DELTA sequence --
+  // so a delta tap that falls outside the utterance takes the delta of the edge row, not the
+  // regression over a shifted window.
+  auto emit_rows = [&](int r_first) {
+    const int r = r_first + 4 * wave + g4;
+    const int r_wave = r_first + 4 * wave;  // wave-uniform
+    const bool interior = r_wave >= kHalo && r_wave + 3 + kHalo <= nframes - 1;
+    float v[9], d[5];
+    if (interior) {
+      const float* const w0 = ring + ((r - kHalo - s_lo + 8) & 31) * RP + q;
+#pragma unroll
+      for (int m = 0; m < 9; ++m) v[m] = w0[m * RP];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) d[k] = regress(v[k], v[k + 1], v[k + 2], v[k + 3], v[k + 4]);
+    } else {
+      asm volatile("" ::: "memory");  // keeps this rare path a real branch: nothing of it is hoisted
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {
+        const int t = min(max(r - kHalo + m, 0), nframes - 1);
+        v[m] = ring[((t - s_lo + 8) & 31) * RP + q];
+      }
+      float e[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) e[k] = regress(v[k], v[k + 1], v[k + 2], v[k + 3], v[k + 4]);
+      const int u = nframes - 1 - r;  // rows left above r; r itself = rows left below
+      d[2] = e[2];
+      d[1] = r == 0 ? e[2] : e[1];                          // row r-1 < 0: delta of row 0
+      d[0] = r == 0 ? e[2] : (r == 1 ? e[1] : e[0]);        // row r-2 < 0
+      d[3] = u == 0 ? e[2] : e[3];                          // row r+1 beyond the last row
+      d[4] = u == 0 ? e[2] : (u == 1 ? e[3] : e[4]);
+    }
+    if (q < ncep && r >= t0 && r < t0 + nt) {
+      float* const o = out_t0 + (r - t0) * ld + q;
+      o[0] = v[4];
+      o[ncep] = d[2];
+      o[2 * ncep] = regress(d[0], d[1], d[2], d[3], d[4]);
+    }
+  };
 
 #ifdef MFCC_DIAG
   unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -644,7 +689,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         if (floor_mel && v == 0.f) v = kEps64;  // wave-uniform flag: the unfloored default pays nothing
         lm[r] = 4 * g4 + r < mel_nf ? fast_ln(v) : 0.f;
       }
-      if (g4 == 3) epbuf[wave * kBatch + q] = acc[3];
+      float* const tile_w = part + wave * kPartTile;
+      if (g4 == 3) tile_w[((q >> 2) * kPartSlots + 16) * 4 + (q & 3)] = acc[3];
       if (OUT == kOutLogmel) {
         const int t = tb + q;
         if (t < s_hi) {
@@ -658,9 +704,11 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         f32x4 pd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) pd = __builtin_amdgcn_mfma_f32_16x16x4f32(dw[r], lm[r], pd, 0, 0, 0);
-        *(f32x4*)__builtin_assume_aligned(lbuf + wave * kPartTile + q * kPartPitch + 4 * g4, 16) = pd;
+        *(f32x4*)__builtin_assume_aligned(tile_w + (g4 * kPartSlots + q) * 4, 16) = pd;
       }
     }
+    // rows of the batch before last whose +-4-row context is now complete leave as whole output rows
+    if (OUT == kOutMfcc39 && tb > s_lo) emit_rows(tb - kBatch - kHalo);
     MFCC_STAMP(tb3);
 #ifndef MFCC_ABL_STAGE
     if (more) delta = stage_st(tb + kBatch);
@@ -669,29 +717,35 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     __syncthreads();  // ln-mel rows and energy partials complete; next batch staged
     MFCC_STAMP(tb5);
 
+    // energy partials of frame slot i: spare slot of coefficient block i / 4 in every wave's tile
+    auto energy_of = [&](int i) {
+      const float* const ee = part + ((i >> 2) * kPartSlots + 16) * 4 + (i & 3);
+      float e = (ee[0] + ee[kPartTile]) + (ee[2 * kPartTile] + ee[3 * kPartTile]);
+      if (e == 0.f) e = kEps64;  // mfcc-self5.py:130-132
+      return fast_ln(e);
+    };
     if (OUT == kOutLogmel) {
       // the ln-mel columns went out from registers; the energy column needs the four partials
-      if (tid < kBatch && tb + tid < s_hi) {
-        float e = (epbuf[tid] + epbuf[16 + tid]) + (epbuf[32 + tid] + epbuf[48 + tid]);
-        if (e == 0.f) e = kEps64;
-        out_t0[(tb - t0 + tid) * ld + nmel] = fast_ln(e);
-      }
-      continue;  // epbuf is rewritten only after the next spectrum barrier
+      if (tid < kBatch && tb + tid < s_hi) out_t0[(tb - t0 + tid) * ld + nmel] = energy_of(tid);
+      continue;  // the tiles are rewritten only after the next spectrum barrier
     }
     {
       // ---- sum of the four DCT shares, c0 := ln E (floored at the float64 epsilon,
       // mfcc-self5.py:130-132 and :164); wave w finishes frames 4 w .. 4 w + 3, lane = (frame, coefficient)
       const int i = 4 * wave + g4;
       const int t = tb + i;
-      const float* const pp = lbuf + i * kPartPitch + q;
+      const float* const pp = part + ((q >> 2) * kPartSlots + i) * 4 + (q & 3);
       float v = (pp[0] + pp[kPartTile]) + (pp[2 * kPartTile] + pp[3 * kPartTile]);
-      float e = (epbuf[i] + epbuf[16 + i]) + (epbuf[32 + i] + epbuf[48 + i]);
-      if (e == 0.f) e = kEps64;
-      e = fast_ln(e);
+      const float e = energy_of(i);
       if (q == 0) v = e;
-      if (q < ncep) {
-        if ((unsigned)(t - t0) < (unsigned)nt) out_t0[(t - t0) * ld + q] = v;
-        else if (t < s_hi) hbuf[(t < t0 ? t - s_lo : kHalo + t - (t0 + nt)) * kMaxCep + q] = v;
+      if (q < ncep && t < s_hi) {
+        if (OUT == kOutMfcc39) {
+          const int rho = (t - s_lo + 8) & 31;
+          ring[rho * RP + q] = v;
+          if (rho < 8) ring[(rho + 32) * RP + q] = v;
+        } else {
+          out_t0[(t - t0) * ld + q] = v;
+        }
       }
     }
 #ifdef MFCC_DIAG
@@ -711,75 +765,12 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   dsum[6] = tk1 - tk0;
 #endif
 
-#ifdef MFCC_ABL_EPI
-  if (OUT == kOutMfcc39 && nt < 0) {
-#else
   if (OUT == kOutMfcc39) {
-#endif
-    // ---- epilogue: statics back from L2, delta, delta-delta, remaining columns out ----------
-    // Thread (c, chunk) = (tid & 15, tid >> 4) owns column c of a run of consecutive rows and
-    // slides a 5-row window down it: one LDS read per row and no index division.
-    __syncthreads();  // all static columns of the tile are written and visible to this workgroup
-    const int ns = s_hi - s_lo;
-    const int d_lo = max(0, t0 - 2), d_hi = min(nframes, t0 + nt + 2);
-    float* const sb = xbuf;              // statics of rows s_lo .. s_hi-1, [ns][ncep]
-    float* const db = xbuf + ns * ncep;  // deltas  of rows d_lo .. d_hi-1
-    const int c = tid & 15, chunk = tid >> 4;
-    const bool col = c < ncep;
-    if (col) {
-      // halo rows come from LDS, the tile's own rows from the output (L2-hot)
-      if (chunk < kHalo) {
-        if (chunk < t0 - s_lo) sb[chunk * ncep + c] = hbuf[chunk * kMaxCep + c];
-      } else if (chunk < 2 * kHalo) {
-        const int k = chunk - kHalo;
-        if (k < s_hi - (t0 + nt)) sb[(t0 - s_lo + nt + k) * ncep + c] = hbuf[chunk * kMaxCep + c];
-      }
-      const int R = (nt + 15) >> 4;
-      const int i0 = chunk * R, i1 = min(nt, i0 + R);
-      float* const dst = sb + (t0 - s_lo) * ncep + c;
-      const float* const src = out_t0 + c;
-      for (int i = i0; i < i1; i += 4) {
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = src[min(i + j, i1 - 1) * ld];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (i + j < i1) dst[(i + j) * ncep] = v[j];
-      }
-    }
+    // the rows still held back: from 4 rows before the last batch to the tile's end (at most 20)
     __syncthreads();
-    // (-2a - b + 0m + d + 2e) / 10 over rows clamped to the utterance (mfcc-self5.py:174-178);
-    // the zero-weight centre tap keeps NaN propagation identical to np.dot over the window.
-    // src holds rows lo..hi of the input; rows [t_lo, t_hi) are produced, written to the output
-    // column block at out_col where they belong to the tile, and kept in LDS if keep != nullptr.
-    auto delta_pass = [&](const float* src, int lo, int hi, int t_lo, int t_hi, float* keep, int out_col) {
-      const int R = (t_hi - t_lo + 15) >> 4;
-      const int ta = t_lo + chunk * R, tz = min(t_hi, ta + R);
-      if (!col || ta >= tz) return;
-      const float* const S = src + c - lo * ncep;  // S[t * ncep] = value of row t
-      float a = S[max(ta - 2, lo) * ncep], b = S[max(ta - 1, lo) * ncep], m = S[ta * ncep], d = S[min(ta + 1, hi) * ncep];
-      for (int t = ta; t < tz; t += 4) {
-        float e[4], v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = S[min(t + 2 + j, hi) * ncep];
-        v[0] = (2.f * (e[0] - a) + (d - b) + 0.f * m) * 0.1f;
-        v[1] = (2.f * (e[1] - b) + (e[0] - m) + 0.f * d) * 0.1f;
-        v[2] = (2.f * (e[2] - m) + (e[1] - d) + 0.f * e[0]) * 0.1f;
-        v[3] = (2.f * (e[3] - d) + (e[2] - e[0]) + 0.f * e[1]) * 0.1f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int tt = t + j;
-          if (tt < tz) {
-            if (keep) keep[(tt - t_lo) * ncep + c] = v[j];
-            if (tt >= t0 && tt < t0 + nt) out_t0[(tt - t0) * ld + out_col + c] = v[j];
-          }
-        }
-        a = e[0]; b = e[1]; m = e[2]; d = e[3];
-      }
-    };
-    delta_pass(sb, s_lo, s_hi - 1, d_lo, d_hi, db, ncep);
-    __syncthreads();
-    delta_pass(db, d_lo, d_hi - 1, t0, t0 + nt, nullptr, 2 * ncep);
+    const int tb_last = s_lo + ((s_hi - s_lo - 1) / kBatch) * kBatch;
+    emit_rows(tb_last - kHalo);
+    if (tb_last + kBatch - kHalo < t0 + nt) emit_rows(tb_last + kBatch - kHalo);
   }
 #ifdef MFCC_DIAG
   {

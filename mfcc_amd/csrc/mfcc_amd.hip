@@ -140,7 +140,6 @@ struct mfcc_plan {
   mfcc::PlanConst pc_host;
   mfcc::PlanConst* pc = nullptr;
   float* melB = nullptr;
-  float* dctB = nullptr;
   float* dctA = nullptr;
   float* window = nullptr;
   float pre_hi, pre_lo, spec_scale;
@@ -189,8 +188,10 @@ extern "C" void mfcc_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p;
 static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int64_t n_tiles, int32_t out_kind, bool i16,
                          hipStream_t st) {
   const dim3 grid((unsigned)n_tiles), block(256);
-  const size_t smem = mfcc::kSmemFloats * sizeof(float) + MFCC_EXTRA_SMEM;
   const bool c13 = plan->cfg.numcep == 13;
+  // kernels with a compile-time numcep of 13 keep 13 floats per row of their statics ring, the others kMaxCep
+  const bool ring13 = c13 && (out_kind == MFCC_OUT_MFCC39 || out_kind == MFCC_OUT_STATIC);
+  const size_t smem = mfcc::smem_floats(ring13 ? 13 : mfcc::kMaxCep) * sizeof(float) + MFCC_EXTRA_SMEM;
   const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
 #define MFCC_LAUNCH_G(OUT, NCEP, G)                                                                          \
   do {                                                                                                       \
@@ -386,13 +387,6 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   }
   pmap.ndct = (nmel + 3) / 4;
   const std::vector<double> dl = mfcc::dct_lifter(nmel, cfg->numcep, cfg->lift_factor, true);
-  std::vector<float> dctB((size_t)mfcc::kDctSteps * 64, 0.f);
-  for (int sidx = 0; sidx < pmap.ndct; ++sidx)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int m = 4 * sidx + (lane >> 4), c = lane & 15;
-      if (m < nmel && c < cfg->numcep)  // [step/2][lane][step%2]: two k-steps of a lane are 8 contiguous bytes
-        dctB[((size_t)(sidx / 2) * 64 + lane) * 2 + sidx % 2] = (float)dl[(size_t)m * cfg->numcep + c];
-    }
   // per-wave weights of the chained product (see PlanConst::dctA)
   std::vector<float> dctA((size_t)4 * 64 * 4, 0.f);
   for (int g = 0; g < 4; ++g)
@@ -410,13 +404,12 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   }
   int rc;
   if ((rc = upload(mfcc::twiddle512(), &p->tw512)) ||
-      (rc = upload(melB, &p->melB)) || (rc = upload(dctB, &p->dctB)) || (rc = upload(dctA, &p->dctA)) || (rc = upload(win, &p->window))) {
+      (rc = upload(melB, &p->melB)) || (rc = upload(dctA, &p->dctA)) || (rc = upload(win, &p->window))) {
     mfcc_plan_destroy(p);
     return rc;
   }
   pch.tw512 = p->tw512;
   pch.melB = p->melB;
-  pch.dctB = p->dctB;
   pch.dctA = p->dctA;
   pch.window = p->window;
   pch.nmel = nmel;
@@ -439,7 +432,6 @@ int mfcc_plan_destroy(mfcc_plan* p) {
   if (!p) return MFCC_OK;
   (void)hipFree(p->tw512);
   (void)hipFree(p->melB);
-  (void)hipFree(p->dctB);
   (void)hipFree(p->dctA);
   (void)hipFree(p->window);
   (void)hipFree(p->pc);
