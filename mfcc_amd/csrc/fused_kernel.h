@@ -150,6 +150,7 @@ struct FusedParams {
   float* out;
   int64_t out_ld;
   const PlanConst* pc;
+  int32_t stack_n;            // stacked kinds: frames per context window N (N % 4 == 1); out_ld = N * bins
 #ifdef MFCC_DIAG
   unsigned long long* dbg;    // [n_tiles][4 waves][8] cycle sums
 #endif
@@ -163,7 +164,8 @@ struct FusedParams {
 #define MFCC_STAMP(var)
 #endif
 
-enum : int { kOutMfcc39 = 0, kOutStatic = 1, kOutLogmel = 2, kOutSpec = 3, kOutLogspec = 4 };
+enum : int { kOutMfcc39 = 0, kOutStatic = 1, kOutLogmel = 2, kOutSpec = 3, kOutLogspec = 4,
+             kOutSpecStack = 5, kOutLogspecStack = 6 };  // spectrum rows stacked over N frames (context windows)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -332,7 +334,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const ring = part + kPartFloats;
   float* const twl = ring + kRingRows * RP;
 
-  constexpr bool kSpecOut = (OUT == kOutSpec || OUT == kOutLogspec);
+  constexpr bool kStack = (OUT == kOutSpecStack || OUT == kOutLogspecStack);
+  constexpr bool kSpecOut = (OUT == kOutSpec || OUT == kOutLogspec || kStack);
+  constexpr bool kLogOut = (OUT == kOutLogspec || OUT == kOutLogspecStack);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -560,7 +564,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #endif
       wave_sync();  // every lane of this wave has read its row before spectrum rows overwrite it
 
-      if (OUT != kOutSpec && OUT != kOutLogspec) {
+      if (!kSpecOut) {
         // fetch the filterbank operands of this wave now (L2 latency ~ the untangle below)
 #pragma unroll
         for (int s = 0; s < kMelSteps; s += 4) {
@@ -568,14 +572,18 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           bv[s] = w4.x; bv[s + 1] = w4.y; bv[s + 2] = w4.z; bv[s + 3] = w4.w;
         }
       }
-      float* const P = xbuf + fb * 512 + row_skew(fb);
+      // Stacked kinds keep the finished spectrum rows in LDS, each shifted by the 16-byte phase
+      // (0..3 floats) its copies will have in the output, so that the scatter below moves aligned
+      // 16-byte chunks: element c of frame s lands at output float (f_off + t) N B + f B + c with
+      // s = t + f - h, which is congruent to f_off + s + h + c mod 4 for B = 257 and N % 4 == 1.
+      float* const P = xbuf + fb * 512 + row_skew(fb) + (kStack ? (int)((f_off + tb + fb + (p.stack_n >> 1)) & 3) : 0);
       // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
-      float* const spec_row = (kSpecOut && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
+      float* const spec_row = (kSpecOut && !kStack && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
       const float spec_scale = kSpecOut ? pc->spec_scale : 0.f, spec_floor = kSpecOut ? pc->log_floor : 0.f;
       auto spec_value = [&](float p4) {
         // LDS rows would hold 4|X|^2 (power) or, after the square root, 2|X| (magnitude)
         float v = (mag ? __builtin_amdgcn_sqrtf(p4) : p4) * spec_scale;
-        if (OUT == kOutLogspec) v = fast_ln(fmaxf(v, spec_floor));  // floor 0 = none: ln 0 = -inf as np.log
+        if (kLogOut) v = fast_ln(fmaxf(v, spec_floor));  // floor 0 = none: ln 0 = -inf as np.log
         return v;
       };
       // Z[256-k] lives in the partner lane: fetch four partners and four untangle twiddles at
@@ -599,7 +607,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #else
           lo = x[h + s].x + pb[s].x + pw[s].x; hi = x[h + s].y + pb[s].y + pw[s].y;
 #endif
-          if (kSpecOut) {
+          if (kStack) {
+            P[q + 16 * (h + s)] = spec_value(lo);
+            P[256 - q - 16 * (h + s)] = spec_value(hi);
+          } else if (kSpecOut) {
             // spectrum kinds: scale (sqrt, ln) and write the two bins of this lane straight from
             // registers to the output row of the frame; no trip through LDS, no barrier
             if (spec_row) {
@@ -613,7 +624,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         }
       }
       if (q == 0) {  // bin 128 pairs with itself: X[128] = conj Z[128]
-        if (kSpecOut) {
+        if (kStack) {
+          P[128] = spec_value(4.f * norm2(x[8]));
+        } else if (kSpecOut) {
           if (spec_row) spec_row[128] = spec_value(4.f * norm2(x[8]));
         } else {
           P[128] = 4.f * norm2(x[8]);
@@ -638,6 +651,65 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     MFCC_STAMP(tb2);
     const bool more = tb + kBatch < s_hi;
 
+    if (kStack) {
+      // ---- context stacking (padUtterance + slidingWin, MLP_5hidlayer_40.py:70-105), write-driven:
+      // out[t, f B + c] = spec[clamp(t + f - h), c], so the row of frame s is the column block
+      // f = s - t + h of the output rows t = s - h .. s + h (inside the utterance), and the first /
+      // last frame also fills the blocks whose window index was clamped.  Every (frame, output row)
+      // pair is one 1028-byte copy LDS -> HBM done by one wave: 16-byte chunks (plain stores: L2
+      // merges the chunks and the edge floats of neighbouring blocks into whole lines; non-temporal
+      // stores measured 6 % slower here) plus up to three single floats at each end.
+      stage_ld(tb + kBatch);
+      constexpr int B = kNbin;
+      const int N = p.stack_n, hN = N >> 1;
+      const int64_t W = (int64_t)N * B;
+      float* const out_u = p.out + f_off * W;  // output row 0 of this utterance
+      const int nrow = min(kBatch, s_hi - tb);
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      // wave w scatters frame slots w, w + 4, w + 8, w + 12: the row is read from LDS once and
+      // stored to each of its output rows (consecutive t, block f falling: + (W - B) floats a step)
+      for (int i = wave; i < nrow; i += 4) {
+        const int sfrm = tb + i;
+        const int a = (int)((f_off + sfrm + hN) & 3);  // phase of the row: LDS and output alike
+        const float* const src = xbuf + i * 512 + row_skew(i) + a;
+        const int c0 = (4 - a) & 3, nbody = (B - c0) >> 2, ntail = B - c0 - 4 * nbody;
+        const bool body = lane < nbody, edge = lane < c0 + ntail;
+        const int ce = lane < c0 ? lane : 4 * nbody + lane;  // head floats 0 .. c0-1, tail floats after the chunks
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        float ve = 0.f;
+        if (body) v = *(const f32x4_t*)__builtin_assume_aligned(src + c0 + 4 * lane, 16);
+        if (edge) ve = src[ce];
+        const int j_lo = max(0, hN - sfrm), j_hi = min(N - 1, nframes - 1 - sfrm + hN);  // t = sfrm - h + j inside [0, F)
+        float* d = out_u + (int64_t)(sfrm - hN + j_lo) * W + (int64_t)(N - 1 - j_lo) * B;
+        for (int j = j_lo; j <= j_hi; ++j, d += W - B) {
+          if (body) *(f32x4_t*)__builtin_assume_aligned(d + c0 + 4 * lane, 16) = v;
+          if (edge) d[ce] = ve;
+        }
+      }
+      // Clamped windows: blocks f < h - t of the rows t < h take frame 0, blocks f > F - 1 - t + h of
+      // the last h rows take frame F - 1.  Their phase differs from the row's: single floats.
+      auto copy_any = [&](int i, int64_t dst) {
+        const int a = (int)((f_off + tb + i + hN) & 3);
+        const float* const src = xbuf + i * 512 + row_skew(i) + a;
+        float* const d = out_u + dst;
+        for (int c = lane; c < B; c += 64) d[c] = src[c];
+      };
+      if (tb == 0) {
+        int k = 0;
+        for (int t = 0; t < min(hN, nframes); ++t)
+          for (int f = 0; f < hN - t; ++f, ++k)
+            if ((k & 3) == wave) copy_any(0, (int64_t)t * W + (int64_t)f * B);
+      }
+      if (tb + nrow == nframes) {
+        int k = 0;
+        for (int t = max(0, nframes - hN); t < nframes; ++t)
+          for (int f = nframes - t + hN; f < N; ++f, ++k)
+            if ((k & 3) == wave) copy_any(nrow - 1, (int64_t)t * W + (int64_t)f * B);
+      }
+      if (more) delta = stage_st(tb + kBatch);
+      __syncthreads();
+      continue;
+    }
     if (kSpecOut) {
       // rows are already written; the barrier above only released the staged audio
       stage_ld(tb + kBatch);

@@ -183,6 +183,9 @@ extern "C" void mfcc_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p;
 #define MFCC_EXTRA_SMEM 0  // occupancy experiments only
 #endif
 
+// launch_fused selectors of the stacked spectrum kinds (not part of the public out_kind values)
+enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101 };
+
 // One workgroup per tile; template arguments select the output kind, a compile-time numcep of 13
 // where it pays, and the sample type.
 static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int64_t n_tiles, int32_t out_kind, bool i16,
@@ -215,6 +218,8 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     case MFCC_OUT_LOGMEL: MFCC_LAUNCH(mfcc::kOutLogmel, 0); break;
     case MFCC_OUT_SPEC: MFCC_LAUNCH(mfcc::kOutSpec, 0); break;
     case MFCC_OUT_LOGSPEC: MFCC_LAUNCH(mfcc::kOutLogspec, 0); break;
+    case kLaunchSpecStack: MFCC_LAUNCH(mfcc::kOutSpecStack, 0); break;
+    case kLaunchLogspecStack: MFCC_LAUNCH(mfcc::kOutLogspecStack, 0); break;
   }
 #undef MFCC_LAUNCH_G
 #undef MFCC_LAUNCH
@@ -617,11 +622,49 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
     fp.total_elems = 1;
   }
   fp.pc = plan->pc;
+  fp.stack_n = 0;
 #ifdef MFCC_DIAG
   fp.dbg = g_dbg;
 #endif
 
   launch_fused(plan, fp, layout->n_tiles, out_kind, audio_dtype == MFCC_AUDIO_I16, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype, int32_t framenum,
+                         float* out, int32_t out_kind, void* stream) {
+  if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: null plan or layout");
+  if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
+  if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: the layout holds frame counts only (mfcc_layout_create_frames)");
+  if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
+  if (out_kind != MFCC_OUT_SPEC && out_kind != MFCC_OUT_LOGSPEC)
+    return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: out_kind must be MFCC_OUT_SPEC or MFCC_OUT_LOGSPEC");
+  if (framenum < 1 || framenum % 2 == 0)
+    return fail(MFCC_ERR_INVALID, "framenum=%d: use an odd number of frames (MLP_5hidlayer_40.py:261-262 warns the same)", framenum);
+  if (framenum % 4 != 1 || framenum > 65)
+    return fail(MFCC_ERR_UNSUPPORTED, "framenum=%d: the one-launch path takes framenum = 1, 5, 9, 13, 17, 21 ... 65 "
+                "(rows keep one 16-byte phase); use mfcc_forward + mfcc_stack_context", framenum);
+  if (layout->n_utts == 0 || layout->n_tiles == 0) return MFCC_OK;
+  if (!out || !audio) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: null device pointer");
+  if ((uintptr_t)out & 15) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: out must be 16-byte aligned");
+
+  mfcc::FusedParams fp;
+  fp.audio = audio;
+  fp.sample_off = layout->d_sample_off;
+  fp.sample_len = nullptr;
+  fp.frame_off = layout->d_frame_off;
+  fp.tiles = layout->d_tiles;
+  fp.out = out;
+  fp.out_ld = (int64_t)framenum * (plan->nfft / 2 + 1);
+  fp.total_elems = layout->total_samples;
+  fp.pc = plan->pc;
+  fp.stack_n = framenum;
+#ifdef MFCC_DIAG
+  fp.dbg = nullptr;
+#endif
+  launch_fused(plan, fp, layout->n_tiles, out_kind == MFCC_OUT_SPEC ? kLaunchSpecStack : kLaunchLogspecStack,
+               audio_dtype == MFCC_AUDIO_I16, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
 }
@@ -939,6 +982,7 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
     fp.out = s->stat;
     fp.out_ld = mfcc::kMaxCep;
     fp.pc = plan->pc;
+    fp.stack_n = 0;
 #ifdef MFCC_DIAG
     fp.dbg = nullptr;
 #endif

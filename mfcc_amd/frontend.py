@@ -317,13 +317,31 @@ def spectrum257(audio, lengths=None, preemph=0.97, spectrum="power", window=None
                   kind="logspec" if log else "spec")
 
 
-def spectrum_stack(fe, audio, layout, framenum, out=None, log=True, spec=None):
+def spectrum_stack(fe, audio, layout, framenum, out=None, log=True):
     """The "257 coefficients x N frames" input of the MLP/CNN scripts (MLP_5hidlayer_40.py:244-248)
     straight from audio: spectrum rows of ``fe`` (ln of them when ``log``) stacked over ``framenum``
-    frames with edge replication per utterance -> float32 [sum F, framenum * (nfft/2+1)]."""
-    kind = "logspec" if log else "spec"
-    spec = fe.forward(audio, layout, out=spec, kind=kind)
-    return stack_context(spec, framenum, frame_counts=np.diff(layout.frame_offsets), out=out)
+    frames with edge replication per utterance -> float32 [sum F, framenum * (nfft/2+1)].  One launch
+    when framenum % 4 == 1 (each 257-bin row is computed once and written framenum times); other odd
+    values go through ``forward`` + ``stack_context``."""
+    if not audio.is_cuda or not audio.is_contiguous() or audio.dtype not in (torch.int16, torch.float32):
+        raise ValueError("audio must be a contiguous int16 or float32 device tensor")
+    if audio.numel() != layout.total_samples:
+        raise ValueError(f"audio has {audio.numel()} samples, layout expects {layout.total_samples}")
+    framenum = int(framenum)
+    width = fe.plan.out_width("spec")
+    shape = (layout.total_frames, framenum * width)
+    if framenum % 4 != 1 or framenum > 65:
+        spec = fe.forward(audio, layout, kind="logspec" if log else "spec")
+        return stack_context(spec, framenum, frame_counts=np.diff(layout.frame_offsets), out=out)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=audio.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.data_ptr() % 16:
+        raise ValueError(f"out must be a contiguous, 16-byte aligned float32 {shape} device tensor")
+    code = capi.AUDIO_I16 if audio.dtype == torch.int16 else capi.AUDIO_F32
+    with _on(fe.plan.device, audio, out):
+        capi.check(capi.load().mfcc_forward_stacked(fe.plan._h, layout._h, _ptr(audio), code, framenum, _ptr(out),
+                                                    capi.OUT_LOGSPEC if log else capi.OUT_SPEC, _stream_ptr()))
+    return out
 
 
 _frame_layouts = {}

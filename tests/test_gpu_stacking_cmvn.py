@@ -200,3 +200,38 @@ def test_log_spectrum_against_oracle(M, golden):
         spec = np.exp(ref)
         tol = 2e-6 * spec.max(axis=1, keepdims=True) / np.maximum(spec, 1e-300) + 2e-6 * np.maximum(np.abs(ref), 1)
         assert (np.abs(lg - ref)[fin] <= tol[fin]).all()
+
+
+@pytest.mark.parametrize("variant,log", [("self5", True), ("self15", False)])
+def test_spectrum_stack_one_launch_equals_two_kernels(M, variant, log):
+    """mfcc_forward_stacked (spectrum rows computed once, written framenum times) against
+    mfcc_forward + mfcc_stack_context bit for bit (both copy the same float32 spectrum values), on a
+    ragged batch with one-frame, shorter-than-window, tile-sized and multi-tile utterances, and
+    against the oracle's stacking of its own spectrum."""
+    rng = np.random.default_rng(33)
+    frames = [1, 2, 3, 8, 9, 16, 17, 40, 299, 304, 305, 700]
+    lengths = [400 + 160 * (f - 1) - int(rng.integers(0, 160)) if f > 1 else 123 for f in frames]
+    audios = [np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths]
+    fe = M.MFCC(variant)
+    lay = fe.layout(lengths)
+    packed = torch.from_numpy(np.concatenate(audios)).cuda()
+    spec = fe.forward(packed, lay, kind="logspec" if log else "spec")
+    counts = np.diff(lay.frame_offsets)
+    assert list(counts) == frames
+    for framenum in (17, 5, 1):
+        two = M.stack_context(spec, framenum, frame_counts=counts)
+        one = M.spectrum_stack(fe, packed, lay, framenum, log=log)
+        assert one.shape == (sum(frames), framenum * 257)
+        assert torch.equal(one, two)
+    # framenum % 4 == 3 takes the two-kernel route inside the same call
+    assert torch.equal(M.spectrum_stack(fe, packed, lay, 11, log=log), M.stack_context(spec, 11, frame_counts=counts))
+    # and the values are the reference's: spectrum of the oracle, stacked by the oracle
+    u = 7                                                              # the 40-frame utterance
+    ref = O.stack_context(O.spectrum257(audios[u], variant, log=log), 17)
+    got = M.spectrum_stack(fe, packed, lay, 17, log=log)[lay.frame_offsets[u]:lay.frame_offsets[u + 1]].cpu().numpy()
+    if log:
+        assert np.abs(got - ref).max() < 2e-3        # ln of bins far below the row maximum, see test_log_spectrum_against_oracle
+    else:
+        assert (np.abs(got - ref) <= 2e-6 * np.abs(ref).max()).all()
+    with pytest.raises(ValueError):
+        M.spectrum_stack(fe, packed, lay, 17, out=torch.empty(3, 3, device="cuda"))
