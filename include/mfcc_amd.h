@@ -45,6 +45,14 @@ extern "C" {
 #define MFCC_WINDOW_NONE 0
 #define MFCC_WINDOW_HAMMING 1
 
+/* Which kernel a plan runs.  AUTO takes the kernel specialised for the reference's own framings
+ * (400/160 samples at 16 kHz, 200/80 at 8 kHz, 512-point FFT, pad_fac 2, <= 40 filters, <= 16
+ * cepstra) when the configuration fits it and the general one otherwise, which covers every other
+ * (fs, frame_time, step_time) winfft accepts (mfcc-self5.py:75-84: frame sizes up to 2048 samples,
+ * FFT lengths 2 .. 2048) and any pad_fac of delta (:169).  GENERAL forces the general kernel. */
+#define MFCC_KERNEL_AUTO 0
+#define MFCC_KERNEL_GENERAL 1
+
 /* what mfcc_forward writes, one row per frame */
 #define MFCC_OUT_MFCC39 0  /* [F, 3*numcep]  c | delta | delta-delta   (mfcc-self5.py:181-186) */
 #define MFCC_OUT_STATIC 1  /* [F, numcep]    c0 := ln E               (mfcc-self5.py:158-167) */
@@ -78,6 +86,9 @@ typedef struct mfcc_config {
                              (spec_anal, anal_recog_nn_liste.m:503)                     */
   double log_floor;   /* MFCC_OUT_LOGSPEC takes ln(max(v, log_floor)) when > 0: the log(max(|X|, 1)) of
                          spec_anal, anal_recog_nn_liste.m:529; 0 = plain ln            */
+  double high_freq;   /* 0 = fs/2, the upper edge melbanks always uses (mfcc-self5.py:103); otherwise the
+                         upper edge in Hz (the highfreq argument of the CTC scripts' MFCC routine) */
+  int32_t kernel;     /* MFCC_KERNEL_*                                             */
 } mfcc_config;
 
 typedef struct mfcc_plan mfcc_plan;     /* immutable constant tables on one device          */
@@ -104,6 +115,8 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out);
 int mfcc_plan_destroy(mfcc_plan* plan);
 int mfcc_plan_info(const mfcc_plan* plan, int32_t* frame_size, int32_t* frame_step, int32_t* num_fft,
                    int32_t* num_bins, int32_t* numcep);
+/* MFCC_KERNEL_GENERAL if the plan runs the general kernel, MFCC_KERNEL_AUTO (0) if the specialised one */
+int32_t mfcc_plan_kernel(const mfcc_plan* plan);
 
 /* ---- batch layout ---------------------------------------------------------- */
 /* n_utts utterances stored back to back: utterance u occupies samples

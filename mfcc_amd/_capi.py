@@ -19,6 +19,7 @@ SPECTRUM_POWER, SPECTRUM_MAG = 0, 1
 WINDOW_NONE, WINDOW_HAMMING = 0, 1
 OUT_MFCC39, OUT_STATIC, OUT_LOGMEL, OUT_SPEC, OUT_LOGSPEC = 0, 1, 2, 3, 4
 STACK_FRAME_MAJOR, STACK_TILE = 0, 1
+KERNEL_AUTO, KERNEL_GENERAL = 0, 1
 CMVN_STATIC_MAX_COLS = 264
 
 
@@ -40,6 +41,8 @@ class MfccConfig(C.Structure):
         ("num_fft", C.c_int32),
         ("frame_rule", C.c_int32),
         ("log_floor", C.c_double),
+        ("high_freq", C.c_double),
+        ("kernel", C.c_int32),
     ]
 
 
@@ -64,6 +67,7 @@ SIGNATURES = {
     "mfcc_plan_create": (C.c_int, [C.POINTER(MfccConfig), C.c_int, C.POINTER(_vp)]),
     "mfcc_plan_destroy": (C.c_int, [_vp]),
     "mfcc_plan_info": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, _i32p]),
+    "mfcc_plan_kernel": (_i32, [_vp]),
     "mfcc_layout_create": (C.c_int, [_vp, _i64p, _i64, C.POINTER(_vp)]),
     "mfcc_layout_create_frames": (C.c_int, [C.c_int, _i64p, _i64, C.POINTER(_vp)]),
     "mfcc_layout_destroy": (C.c_int, [_vp]),

@@ -1,0 +1,227 @@
+// General-geometry MFCC kernel: the same pipeline as fused_kernel.h for every framing the
+// reference's winfft can derive (frame_size = int(fs * frame_time / 1000), num_fft = next power of
+// two, mfcc-self5.py:75-84), any pad_fac of delta (:169-179) and filterbank / cepstrum sizes the
+// specialised kernel has no template for.  Built to be right for every valid call, not to be fast:
+// the 400/160/512 and 200/80/512 framings of the reference's own scripts run in fused_kernel.h.
+//
+// Work decomposition
+//   grid       one workgroup (4 waves) per tile of consecutive output frames of one utterance
+//              (same Tile list as the specialised kernel, shorter tiles);
+//   wave       one frame at a time: the frame_size samples are read from global memory
+//              (pre-emphasised on the fly, zero beyond the utterance end), packed as nfft/2
+//              complex points z[n] = x[2n] + i x[2n+1] into the wave's own LDS buffer in
+//              bit-reversed order, transformed by radix-2 butterflies in LDS (a wave's LDS
+//              operations execute in program order, so no workgroup barrier is needed), untangled
+//              into the nfft/2+1 spectrum values, reduced by the sparse triangular filters (one
+//              lane per filter), ln, DCT-II * lifter (one lane per coefficient);
+//   tile end   the static rows of the tile and its halo (2 * pad_fac frames on each side that
+//              continues) sit in LDS: delta over them, then delta of the deltas, both with the
+//              indices clamped to the utterance (np.pad(mode='edge'), mfcc-self5.py:174).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fused_kernel.h"
+
+namespace mfcc {
+
+constexpr int kGenMaxFft = 2048;   // largest FFT (frame_size <= 2048: 25 ms up to 81.9 kHz)
+constexpr int kGenMaxMel = 128;
+constexpr int kGenMaxCep = 64;
+constexpr int kGenMaxPad = 16;     // pad_fac of delta
+constexpr int kGenMaxTile = 128;   // output frames per tile at most
+
+// Constant tables of a general plan (device memory).
+struct GeneralConst {
+  const float* tw;        // [nfft/2][2]  exp(-2 pi i k / nfft)
+  const float* bank;      // [nmel][nbin] triangular weights (mfcc-self5.py:102-117)
+  const int32_t* band;    // [nmel][2]    first bin with a non-zero weight, one past the last
+  const float* dctl;      // [nmel][numcep] DCT-II 'ortho' * lifter (mfcc-self5.py:136-156)
+  const float* window;    // [frame_size] or nullptr
+  int32_t frame_size, frame_step, nfft, log2m;  // log2m = log2(nfft / 2)
+  int32_t used;           // samples of a frame that enter the FFT = min(frame_size, nfft) (np.fft.rfft truncates)
+  int32_t nmel, numcep, pad_fac;
+  int32_t spectrum, floor_mel;
+  float pre_hi, pre_lo;   // 0, 0 = no pre-emphasis
+  float inv_nfft;         // power spectrum scale 1/nfft (mfcc-self5.py:97)
+  float log_floor;
+  float delta_denom;      // 2 * sum i^2, mfcc-self5.py:172
+  int32_t stat_rows;      // rows of the statics / delta arrays in LDS (>= tile frames + 4 * pad_fac)
+};
+
+// dynamic LDS of the kernel, in floats: per wave a complex FFT buffer, a spectrum row and a
+// ln-mel row; per workgroup the static and delta rows of a tile (MFCC-39 only)
+__host__ __device__ inline int general_row_floats(int nfft) { return (nfft / 2 + 1 + 3) & ~3; }
+__host__ __device__ inline int general_wave_floats(int nfft, int nmel) {
+  return nfft + general_row_floats(nfft) + ((nmel + 1 + 3) & ~3);
+}
+inline size_t general_smem_bytes(int nfft, int nmel, int numcep, int stat_rows) {
+  return ((size_t)4 * general_wave_floats(nfft, nmel) + (size_t)2 * stat_rows * numcep) * sizeof(float);
+}
+
+__device__ __forceinline__ unsigned bit_reverse(unsigned v, int bits) { return bits ? __brev(v) >> (32 - bits) : 0u; }
+
+// y[g] of utterance sample g (0 <= g < len): x[g] - c x[g-1], y[0] = x[0] (mfcc-self5.py:68).  int16
+// input: numpy works in float64, matched by a two-term coefficient and fused multiply-adds;
+// float32 input: numpy works in float32 with two roundings.
+template <typename T>
+__device__ __forceinline__ float preemph_at(const T* __restrict__ x, int64_t g, float pre_hi, float pre_lo) {
+  const float x0 = (float)x[g];
+  if (g == 0 || (pre_hi == 0.f && pre_lo == 0.f)) return x0;
+  const float x1 = (float)x[g - 1];
+  if (sizeof(T) == 2) return fmaf(-pre_lo, x1, fmaf(-pre_hi, x1, x0));
+  return __fsub_rn(x0, __fmul_rn(pre_hi, x1));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const GeneralConst* __restrict__ gcp, int out_kind) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  const GeneralConst gc = *gcp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = gc.nfft >> 1, nbin = M + 1;
+  const int nmel = gc.nmel, ncep = gc.numcep, pf = gc.pad_fac;
+  float* const wbase = gsm + wave * general_wave_floats(gc.nfft, nmel);
+  cf* const z = (cf*)wbase;                               // [M] complex
+  float* const srow = wbase + gc.nfft;                    // [nbin] spectrum row
+  float* const lrow = srow + general_row_floats(gc.nfft); // [nmel] ln mel, then ln E
+  float* const stat = gsm + 4 * general_wave_floats(gc.nfft, nmel);  // [stat_rows][ncep]
+  float* const dlt = stat + gc.stat_rows * ncep;                     // [stat_rows][ncep]
+
+  const Tile tile = p.tiles[blockIdx.x];
+  const int64_t s_off = p.sample_off[tile.utt];
+  const int64_t len = p.sample_len ? p.sample_len[tile.utt] : p.sample_off[tile.utt + 1] - s_off;
+  const int64_t f_off = p.frame_off[tile.utt];
+  const int nframes = (int)(p.frame_off[tile.utt + 1] - f_off);
+  const int t0 = tile.t0, nt = tile.nt;
+  const bool full = out_kind == kOutMfcc39;
+  const int s_lo = full ? max(0, t0 - 2 * pf) : t0;
+  const int s_hi = full ? min(nframes, t0 + nt + 2 * pf) : t0 + nt;
+  const T* const x = (const T*)p.audio + s_off;
+  const int64_t ld = p.out_ld;
+  const bool mag = gc.spectrum != 0;
+
+  for (int t = s_lo + wave; t < s_hi; t += 4) {
+    // ---- framing (mfcc-self5.py:85-95): samples t*step .. +frame_size, zeros past the utterance end
+    const int64_t g0 = (int64_t)t * gc.frame_step;
+    for (int n = lane; n < M; n += 64) {
+      float v[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = 2 * n + j;
+        const int64_t g = g0 + i;
+        float y = 0.f;
+        if (i < gc.used && g < len) {
+          y = preemph_at(x, g, gc.pre_hi, gc.pre_lo);
+          if (gc.window) y *= gc.window[i];
+        }
+        v[j] = y;
+      }
+      z[bit_reverse((unsigned)n, gc.log2m)] = mk(v[0], v[1]);
+    }
+    wave_sync();
+    // ---- nfft/2-point complex FFT, radix-2 decimation in time, in place
+    for (int s = 0; s < gc.log2m; ++s) {
+      const int half = 1 << s;
+      for (int j = lane; j < (M >> 1); j += 64) {
+        const int pos = j & (half - 1);
+        const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
+        const int k = pos << (gc.log2m - s);  // W_M^(pos M / (2 half)) = W_nfft^(pos M / half)
+        const cf w = mk(gc.tw[2 * k], gc.tw[2 * k + 1]);
+        const cf a = z[i0], b = z[i1];
+        const cf bw = mk(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
+        z[i0] = a + bw;
+        z[i1] = a - bw;
+      }
+      wave_sync();
+    }
+    // ---- untangle: X[k] = (A - i W^k B) / 2, A = Z[k] + conj Z[M-k], B = Z[k] - conj Z[M-k];
+    //      spectrum value |X|^2 / nfft or |X| (mfcc-self5.py:96-97)
+    float* const orow = (out_kind == kOutSpec || out_kind == kOutLogspec) && t >= t0 && t < t0 + nt ? p.out + (f_off + t) * ld : nullptr;
+    for (int k = lane; k <= M; k += 64) {
+      float p4;  // 4 |X[k]|^2
+      if (k == 0 || k == M) {
+        const cf z0 = z[0];
+        const float xr = k == 0 ? z0.x + z0.y : z0.x - z0.y;
+        p4 = 4.f * xr * xr;
+      } else {
+        const cf a = z[k], b = z[M - k];
+        const cf A = mk(a.x + b.x, a.y - b.y), B = mk(a.x - b.x, a.y + b.y);
+        const cf w = mk(gc.tw[2 * k], gc.tw[2 * k + 1]);
+        const cf C = mk(B.x * w.x - B.y * w.y, B.x * w.y + B.y * w.x);
+        const float ur = A.x + C.y, ui = A.y - C.x;  // A - i C
+        p4 = ur * ur + ui * ui;
+      }
+      const float v = mag ? 0.5f * sqrtf(p4) : p4 * (0.25f * gc.inv_nfft);
+      srow[k] = v;
+      if (orow) orow[k] = out_kind == kOutLogspec ? logf(fmaxf(v, gc.log_floor)) : v;
+    }
+    wave_sync();
+    if (out_kind == kOutSpec || out_kind == kOutLogspec) continue;
+    // ---- mel energies and frame energy (mfcc-self5.py:119-134): ln of the unfloored band sums
+    //      (-inf on an empty band) unless floor_mel; ln E floored at the float64 epsilon
+    float e = 0.f;
+    for (int k = lane; k < nbin; k += 64) e += srow[k];
+    for (int m = 32; m >= 1; m >>= 1) e += __shfl_xor(e, m, 64);
+    if (e == 0.f) e = kEps64;
+    const float lne = logf(e);
+    for (int j = lane; j < nmel; j += 64) {
+      const int lo = gc.band[2 * j], hi = gc.band[2 * j + 1];
+      const float* const w = gc.bank + (size_t)j * nbin;
+      float acc = 0.f;
+      for (int k = lo; k < hi; ++k) acc = fmaf(srow[k], w[k], acc);
+      if (gc.floor_mel && acc == 0.f) acc = kEps64;
+      lrow[j] = logf(acc);
+    }
+    wave_sync();
+    const bool own = t >= t0 && t < t0 + nt;
+    if (out_kind == kOutLogmel) {
+      if (own) {
+        float* const o = p.out + (f_off + t) * ld;
+        for (int j = lane; j < nmel; j += 64) o[j] = lrow[j];
+        if (lane == 0) o[nmel] = lne;
+      }
+      wave_sync();
+      continue;
+    }
+    // ---- DCT-II * lifter, c0 := ln E (mfcc-self5.py:136-167)
+    for (int c = lane; c < ncep; c += 64) {
+      float acc = 0.f;
+      for (int n = 0; n < nmel; ++n) acc = fmaf(lrow[n], gc.dctl[n * ncep + c], acc);
+      if (c == 0) acc = lne;
+      if (full) stat[(t - s_lo) * ncep + c] = acc;
+      else if (own) p.out[(f_off + t) * ld + c] = acc;
+    }
+    wave_sync();
+  }
+  if (!full) return;
+  __syncthreads();
+  // ---- delta (mfcc-self5.py:169-179) of rows d_lo .. d_hi-1, then delta of the deltas for the
+  //      tile's own rows; both clamp their row indices to the utterance
+  const int d_lo = max(0, t0 - pf), d_hi = min(nframes, t0 + nt + pf);
+  const float denom = gc.delta_denom;
+  for (int i = tid; i < (d_hi - d_lo) * ncep; i += 256) {
+    const int r = d_lo + i / ncep, c = i % ncep;
+    float acc = 0.f;
+    for (int k = -pf; k <= pf; ++k) {
+      const int rr = min(max(r + k, 0), nframes - 1);
+      acc = fmaf((float)k, stat[(rr - s_lo) * ncep + c], acc);
+    }
+    dlt[(r - s_lo) * ncep + c] = acc / denom;
+  }
+  __syncthreads();
+  for (int i = tid; i < nt * ncep; i += 256) {
+    const int r = t0 + i / ncep, c = i % ncep;
+    float acc = 0.f;
+    for (int k = -pf; k <= pf; ++k) {
+      const int rr = min(max(r + k, 0), nframes - 1);
+      acc = fmaf((float)k, dlt[(rr - s_lo) * ncep + c], acc);
+    }
+    float* const o = p.out + (f_off + r) * ld;
+    o[c] = stat[(r - s_lo) * ncep + c];
+    o[ncep + c] = dlt[(r - s_lo) * ncep + c];
+    o[2 * ncep + c] = acc / denom;
+  }
+}
+
+}  // namespace mfcc

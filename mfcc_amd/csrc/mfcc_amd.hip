@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "fused_kernel.h"
+#include "general_kernel.h"
 #include "stage_kernels.h"
 #include "stream_kernels.h"
 #include "tables.h"
@@ -143,6 +144,17 @@ struct mfcc_plan {
   float* dctA = nullptr;
   float* window = nullptr;
   float pre_hi, pre_lo, spec_scale;
+  // general kernel (general_kernel.h): set when the configuration is outside the specialised kernel
+  bool general = false;
+  int32_t gen_nt_max = 0;  // output frames per tile
+  size_t gen_smem = 0;     // dynamic LDS per workgroup
+  mfcc::GeneralConst gc_host;
+  mfcc::GeneralConst* gc = nullptr;
+  float* g_tw = nullptr;
+  float* g_bank = nullptr;
+  int32_t* g_band = nullptr;
+  float* g_dctl = nullptr;
+  float* g_window = nullptr;
 };
 
 struct mfcc_layout {
@@ -154,6 +166,11 @@ struct mfcc_layout {
   mfcc::Tile* d_tiles = nullptr;
   int64_t n_tiles;
   bool frames_only = false;  // made by mfcc_layout_create_frames: frame offsets only, no audio geometry
+  // what the tile list was cut for: a plan may only run on a layout of its own framing whose
+  // tiles fit its kernel
+  int32_t frame_size = 0, frame_step = 0, frame_rule = 0;
+  int32_t max_nt = 0;  // most output frames in one tile
+  bool general_cut = false;  // tiles cut for the general kernel (no halo rule)
 };
 
 struct mfcc_stream {
@@ -191,6 +208,12 @@ enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101 };
 static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int64_t n_tiles, int32_t out_kind, bool i16,
                          hipStream_t st) {
   const dim3 grid((unsigned)n_tiles), block(256);
+  if (plan->general) {
+    // the public out_kind values are the kernel's own
+    if (i16) hipLaunchKernelGGL(mfcc::general_kernel<int16_t>, grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+    else hipLaunchKernelGGL(mfcc::general_kernel<float>, grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+    return;
+  }
   const bool c13 = plan->cfg.numcep == 13;
   // kernels with a compile-time numcep of 13 keep 13 floats per row of their statics ring, the others kMaxCep
   const bool ring13 = c13 && (out_kind == MFCC_OUT_MFCC39 || out_kind == MFCC_OUT_STATIC);
@@ -225,9 +248,24 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
 #undef MFCC_LAUNCH
 }
 
+// A layout's tile list was cut for the plan it was created with; another plan may use it when
+// the framing is the same and every tile fits that plan's kernel.
+static int layout_fits(const mfcc_plan* plan, const mfcc_layout* layout) {
+  if (layout->frame_size != plan->frame_size || layout->frame_step != plan->frame_step || layout->frame_rule != plan->cfg.frame_rule)
+    return fail(MFCC_ERR_INVALID, "the layout was created for frames of %d samples every %d (frame_rule %d), the plan has %d every %d (frame_rule %d)",
+                layout->frame_size, layout->frame_step, layout->frame_rule, plan->frame_size, plan->frame_step, plan->cfg.frame_rule);
+  // the specialised kernel takes the tiles its own rule cut (up to a whole 19-batch tile when the
+  // utterance ends inside it) and any tile that leaves room for a halo on both sides
+  const int cap = plan->general ? plan->gen_nt_max : mfcc::tile_frames_for(plan->cfg.numcep) - 2 * mfcc::kHalo;
+  if (layout->max_nt > cap && (plan->general || layout->general_cut))
+    return fail(MFCC_ERR_INVALID, "the layout's tiles hold up to %d frames, this plan's kernel takes %d: create the layout with this plan",
+                layout->max_nt, cap);
+  return MFCC_OK;
+}
+
 extern "C" {
 
-int mfcc_version(void) { return 100; }
+int mfcc_version(void) { return 101; }
 
 const char* mfcc_last_error(void) { return g_err; }
 
@@ -251,6 +289,8 @@ void mfcc_config_default(mfcc_config* cfg) {
   cfg->num_fft = 0;
   cfg->frame_rule = 0;
   cfg->log_floor = 0.0;
+  cfg->high_freq = 0.0;
+  cfg->kernel = MFCC_KERNEL_AUTO;
 }
 
 int mfcc_melbank_host(double fs, int32_t numbins, double lowfreq, int32_t num_fft, double* out_host) {
@@ -272,52 +312,14 @@ int64_t mfcc_frames_for_length(int64_t n_samples, int32_t frame_size, int32_t fr
   return mfcc::frames_for_length(n_samples, frame_size, frame_step);
 }
 
-int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
-  if (!cfg || !out) return fail(MFCC_ERR_INVALID, "mfcc_plan_create: null argument");
-  *out = nullptr;
-  int32_t size, step, nfft;
-  mfcc::frame_geometry(cfg->fs, cfg->frame_time, cfg->step_time, &size, &step, &nfft);
-  if (cfg->num_fft != 0) nfft = cfg->num_fft;
-  const bool g16k = size == mfcc::Geom16k::kSize && step == mfcc::Geom16k::kStep;
-  const bool g8k = size == mfcc::Geom8k::kSize && step == mfcc::Geom8k::kStep;
-  if (!(g16k || g8k) || nfft != mfcc::kNfft)
-    return fail(MFCC_ERR_UNSUPPORTED,
-                "framing %d/%d samples, %d-point FFT: the gfx950 kernels are built for 400/160/512 "
-                "(fs=16000, 25 ms / 10 ms) and 200/80/512 (fs=8000 with num_fft=512)", size, step, nfft);
-  if (cfg->num_bins < 1 || cfg->num_bins > mfcc::kMaxMel)
-    return fail(MFCC_ERR_UNSUPPORTED, "num_bins=%d outside 1..%d", cfg->num_bins, mfcc::kMaxMel);
-  if (cfg->numcep < 1 || cfg->numcep > mfcc::kMaxCep || cfg->numcep > cfg->num_bins)
-    return fail(MFCC_ERR_UNSUPPORTED, "numcep=%d outside 1..min(%d, num_bins)", cfg->numcep, mfcc::kMaxCep);
-  if (cfg->pad_fac != 2) return fail(MFCC_ERR_UNSUPPORTED, "pad_fac=%d: the fused kernel implements pad_fac=2", cfg->pad_fac);
-  if (cfg->spectrum != MFCC_SPECTRUM_POWER && cfg->spectrum != MFCC_SPECTRUM_MAG)
-    return fail(MFCC_ERR_INVALID, "spectrum=%d", cfg->spectrum);
-  if (cfg->window != MFCC_WINDOW_NONE && cfg->window != MFCC_WINDOW_HAMMING)
-    return fail(MFCC_ERR_INVALID, "window=%d", cfg->window);
-  if (cfg->low_freq < 0 || cfg->low_freq >= cfg->fs / 2) return fail(MFCC_ERR_INVALID, "low_freq=%g", cfg->low_freq);
-
-  HIP_TRY(hipSetDevice(device));
-  {
-    // set-up time is where the static scratch of mfcc_cmvn_accumulate_static gets its address
-    // on this device (that entry point resolves it itself if no plan was ever created here)
-    double* scratch = nullptr;
-    const int rc_s = cmvn_static_scratch(&scratch);
-    if (rc_s) return rc_s;
-  }
-  mfcc_plan* p = new (std::nothrow) mfcc_plan();
-  if (!p) return fail(MFCC_ERR_NOMEM, "mfcc_plan_create: out of host memory");
-  p->cfg = *cfg;
-  p->device = device;
-  p->frame_size = size;
-  p->frame_step = step;
-  p->nfft = nfft;
-  p->pre_hi = (float)cfg->preemph;
-  p->pre_lo = (float)(cfg->preemph - (double)p->pre_hi);
-  // spectrum rows in LDS hold 4|X|^2 (power) or 2|X| (magnitude); both scales are powers of two
-  p->spec_scale = cfg->spectrum == MFCC_SPECTRUM_POWER ? 1.0f / (4.0f * nfft) : 0.5f;
-
+// Tables of the specialised kernel.  Returns 1 (and leaves the plan without them) when the
+// filterbank does not fit that kernel's fixed number of matrix-core k-steps per wave.
+static int build_specialised(mfcc_plan* p) {
+  const mfcc_config* const cfg = &p->cfg;
+  const int32_t nfft = p->nfft, size = p->frame_size;
   // ---- operands of the two matrix-core products (layout: see mfcc::MelMap) ----------------
   const int nmel = cfg->num_bins;
-  const std::vector<double> bank = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft);
+  const std::vector<double> bank = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft, cfg->high_freq);
   std::vector<int> first(nmel, mfcc::kNbin), last(nmel, -1);
   for (int m = 0; m < nmel; ++m)
     for (int k = 0; k < mfcc::kNbin; ++k)
@@ -362,10 +364,7 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
           for (int g = 0; g < 4; ++g) { best_k0[g] = k0[g]; best_steps[g] = st[g]; }
         }
       }
-  if (best_max > mfcc::kMelSteps) {
-    delete p;
-    return fail(MFCC_ERR_UNSUPPORTED, "filterbank needs %d MFMA k-steps per wave, the kernel provides %d", best_max, mfcc::kMelSteps);
-  }
+  if (best_max > mfcc::kMelSteps) return 1;  // this filterbank does not fit the specialised kernel's k-step budget
   mfcc::PlanConst& pch = p->pc_host;
   memset(&pch, 0, sizeof(pch));
   mfcc::MelMap& pmap = pch.map;
@@ -410,7 +409,6 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   int rc;
   if ((rc = upload(mfcc::twiddle512(), &p->tw512)) ||
       (rc = upload(melB, &p->melB)) || (rc = upload(dctA, &p->dctA)) || (rc = upload(win, &p->window))) {
-    mfcc_plan_destroy(p);
     return rc;
   }
   pch.tw512 = p->tw512;
@@ -426,6 +424,149 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   pch.spec_scale = p->spec_scale;
   pch.log_floor = (float)cfg->log_floor;
   if ((rc = upload(std::vector<mfcc::PlanConst>(1, pch), &p->pc))) {
+    return rc;
+  }
+  return MFCC_OK;
+}
+
+// Tables of the general kernel (see general_kernel.h).
+static int build_general(mfcc_plan* p) {
+  const mfcc_config* const cfg = &p->cfg;
+  const int nfft = p->nfft, nbin = nfft / 2 + 1, nmel = cfg->num_bins, ncep = cfg->numcep, pf = cfg->pad_fac;
+  // LDS budget: 64 KiB per workgroup; what the four waves' FFT buffers leave goes to the tile's
+  // static and delta rows
+  const size_t wave_bytes = (size_t)4 * mfcc::general_wave_floats(nfft, nmel) * sizeof(float);
+  const size_t row_bytes = (size_t)2 * ncep * sizeof(float);
+  const int64_t rows_fit = ((int64_t)65536 - (int64_t)wave_bytes) / (int64_t)row_bytes;
+  const int rows = (int)std::min<int64_t>(rows_fit, mfcc::kGenMaxTile + 4 * pf);
+  if (rows - 4 * pf < 4)
+    return fail(MFCC_ERR_UNSUPPORTED, "num_fft=%d, num_bins=%d, numcep=%d, pad_fac=%d need more LDS than a workgroup has", nfft, nmel, ncep, pf);
+  p->gen_nt_max = rows - 4 * pf;
+  p->gen_smem = mfcc::general_smem_bytes(nfft, nmel, ncep, rows);
+
+  const std::vector<double> bank = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft, cfg->high_freq);
+  std::vector<float> bankf(bank.size());
+  std::vector<int32_t> band((size_t)2 * nmel, 0);
+  for (int m = 0; m < nmel; ++m) {
+    int lo = nbin, hi = 0;
+    for (int k = 0; k < nbin; ++k) {
+      const double w = bank[(size_t)m * nbin + k];
+      bankf[(size_t)m * nbin + k] = (float)w;
+      if (w != 0.0) { lo = std::min(lo, k); hi = std::max(hi, k + 1); }
+    }
+    band[2 * m] = std::min(lo, hi);
+    band[2 * m + 1] = hi;
+  }
+  const std::vector<double> dl = mfcc::dct_lifter(nmel, ncep, cfg->lift_factor, true);
+  std::vector<float> dlf(dl.begin(), dl.end());
+  std::vector<float> win;
+  if (cfg->window == MFCC_WINDOW_HAMMING) {
+    const std::vector<double> h = mfcc::hamming(p->frame_size);
+    win.assign(h.begin(), h.end());
+  }
+  int rc;
+  if ((rc = upload(mfcc::twiddle_half(nfft), &p->g_tw)) || (rc = upload(bankf, &p->g_bank)) || (rc = upload(band, &p->g_band)) ||
+      (rc = upload(dlf, &p->g_dctl)) || (rc = upload(win, &p->g_window)))
+    return rc;
+  mfcc::GeneralConst& g = p->gc_host;
+  memset(&g, 0, sizeof(g));
+  g.tw = p->g_tw;
+  g.bank = p->g_bank;
+  g.band = p->g_band;
+  g.dctl = p->g_dctl;
+  g.window = p->g_window;
+  g.frame_size = p->frame_size;
+  g.frame_step = p->frame_step;
+  g.nfft = nfft;
+  g.log2m = 0;
+  while ((2 << g.log2m) < nfft) ++g.log2m;
+  g.used = std::min(p->frame_size, nfft);
+  g.nmel = nmel;
+  g.numcep = ncep;
+  g.pad_fac = pf;
+  g.spectrum = cfg->spectrum;
+  g.floor_mel = cfg->floor_mel;
+  g.pre_hi = cfg->use_preemph ? p->pre_hi : 0.f;
+  g.pre_lo = cfg->use_preemph ? p->pre_lo : 0.f;
+  g.inv_nfft = 1.0f / (float)nfft;
+  g.log_floor = (float)cfg->log_floor;
+  int denom = 0;
+  for (int i = 1; i <= pf; ++i) denom += 2 * i * i;  // mfcc-self5.py:172
+  g.delta_denom = (float)denom;
+  g.stat_rows = rows;
+  if ((rc = upload(std::vector<mfcc::GeneralConst>(1, g), &p->gc))) return rc;
+  p->general = true;
+  return MFCC_OK;
+}
+
+int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
+  if (!cfg || !out) return fail(MFCC_ERR_INVALID, "mfcc_plan_create: null argument");
+  *out = nullptr;
+  if (!(cfg->fs > 0) || !(cfg->frame_time > 0) || !(cfg->step_time > 0))
+    return fail(MFCC_ERR_INVALID, "fs=%g, frame_time=%g, step_time=%g must be positive", cfg->fs, cfg->frame_time, cfg->step_time);
+  if (cfg->fs * cfg->frame_time > 1e9 || cfg->fs * cfg->step_time > 1e9)
+    return fail(MFCC_ERR_UNSUPPORTED, "fs=%g, frame_time=%g, step_time=%g: frame far beyond %d samples", cfg->fs, cfg->frame_time,
+                cfg->step_time, mfcc::kGenMaxFft);
+  int32_t size, step, nfft;
+  mfcc::frame_geometry(cfg->fs, cfg->frame_time, cfg->step_time, &size, &step, &nfft);
+  if (size < 1 || step < 1)
+    return fail(MFCC_ERR_INVALID, "fs=%g with %g ms frames every %g ms gives frames of %d samples every %d: both must be >= 1", cfg->fs,
+                cfg->frame_time, cfg->step_time, size, step);
+  if (cfg->num_fft != 0) nfft = cfg->num_fft;
+  if (nfft < 2 || nfft > mfcc::kGenMaxFft || (nfft & (nfft - 1)))
+    return fail(MFCC_ERR_UNSUPPORTED, "framing %d/%d samples with a %d-point FFT: the kernels take FFT lengths 2, 4, ... %d "
+                "(frame sizes up to %d samples when num_fft is derived as winfft does)", size, step, nfft, mfcc::kGenMaxFft, mfcc::kGenMaxFft);
+  if (cfg->num_bins < 1 || cfg->num_bins > mfcc::kGenMaxMel)
+    return fail(MFCC_ERR_UNSUPPORTED, "num_bins=%d outside 1..%d", cfg->num_bins, mfcc::kGenMaxMel);
+  if (cfg->numcep < 1 || cfg->numcep > mfcc::kGenMaxCep || cfg->numcep > cfg->num_bins)
+    return fail(MFCC_ERR_UNSUPPORTED, "numcep=%d outside 1..min(%d, num_bins)", cfg->numcep, mfcc::kGenMaxCep);
+  if (cfg->pad_fac < 1 || cfg->pad_fac > mfcc::kGenMaxPad)
+    return fail(MFCC_ERR_UNSUPPORTED, "pad_fac=%d outside 1..%d", cfg->pad_fac, mfcc::kGenMaxPad);
+  if (cfg->spectrum != MFCC_SPECTRUM_POWER && cfg->spectrum != MFCC_SPECTRUM_MAG)
+    return fail(MFCC_ERR_INVALID, "spectrum=%d", cfg->spectrum);
+  if (cfg->window != MFCC_WINDOW_NONE && cfg->window != MFCC_WINDOW_HAMMING)
+    return fail(MFCC_ERR_INVALID, "window=%d", cfg->window);
+  if (cfg->low_freq < 0 || cfg->low_freq >= cfg->fs / 2) return fail(MFCC_ERR_INVALID, "low_freq=%g", cfg->low_freq);
+  if (cfg->high_freq != 0 && (cfg->high_freq <= cfg->low_freq || cfg->high_freq > cfg->fs / 2))
+    return fail(MFCC_ERR_INVALID, "high_freq=%g outside (low_freq, fs/2]", cfg->high_freq);
+  if (cfg->kernel != MFCC_KERNEL_AUTO && cfg->kernel != MFCC_KERNEL_GENERAL) return fail(MFCC_ERR_INVALID, "kernel=%d", cfg->kernel);
+  if (cfg->frame_rule != 0 && cfg->frame_rule != 1) return fail(MFCC_ERR_INVALID, "frame_rule=%d", cfg->frame_rule);
+
+  HIP_TRY(hipSetDevice(device));
+  {
+    // set-up time is where the static scratch of mfcc_cmvn_accumulate_static gets its address
+    // on this device (that entry point resolves it itself if no plan was ever created here)
+    double* scratch = nullptr;
+    const int rc_s = cmvn_static_scratch(&scratch);
+    if (rc_s) return rc_s;
+  }
+  mfcc_plan* p = new (std::nothrow) mfcc_plan();
+  if (!p) return fail(MFCC_ERR_NOMEM, "mfcc_plan_create: out of host memory");
+  p->cfg = *cfg;
+  p->device = device;
+  p->frame_size = size;
+  p->frame_step = step;
+  p->nfft = nfft;
+  p->pre_hi = (float)cfg->preemph;
+  p->pre_lo = (float)(cfg->preemph - (double)p->pre_hi);
+  // spectrum rows in LDS hold 4|X|^2 (power) or 2|X| (magnitude); both scales are powers of two
+  p->spec_scale = cfg->spectrum == MFCC_SPECTRUM_POWER ? 1.0f / (4.0f * nfft) : 0.5f;
+
+  const bool g16k = size == mfcc::Geom16k::kSize && step == mfcc::Geom16k::kStep;
+  const bool g8k = size == mfcc::Geom8k::kSize && step == mfcc::Geom8k::kStep;
+  bool specialised = cfg->kernel == MFCC_KERNEL_AUTO && (g16k || g8k) && nfft == mfcc::kNfft && cfg->num_bins <= mfcc::kMaxMel &&
+                     cfg->numcep <= mfcc::kMaxCep && cfg->pad_fac == 2;
+  int rc = MFCC_OK;
+  try {
+    if (specialised) {
+      rc = build_specialised(p);
+      if (rc == 1) { specialised = false; rc = MFCC_OK; }
+    }
+    if (!specialised && !rc) rc = build_general(p);
+  } catch (const std::bad_alloc&) {
+    rc = fail(MFCC_ERR_NOMEM, "mfcc_plan_create: out of host memory");
+  }
+  if (rc) {
     mfcc_plan_destroy(p);
     return rc;
   }
@@ -440,6 +581,12 @@ int mfcc_plan_destroy(mfcc_plan* p) {
   (void)hipFree(p->dctA);
   (void)hipFree(p->window);
   (void)hipFree(p->pc);
+  (void)hipFree(p->gc);
+  (void)hipFree(p->g_tw);
+  (void)hipFree(p->g_bank);
+  (void)hipFree(p->g_band);
+  (void)hipFree(p->g_dctl);
+  (void)hipFree(p->g_window);
   delete p;
   return MFCC_OK;
 }
@@ -453,6 +600,11 @@ int mfcc_plan_info(const mfcc_plan* p, int32_t* frame_size, int32_t* frame_step,
   if (num_bins) *num_bins = p->cfg.num_bins;
   if (numcep) *numcep = p->cfg.numcep;
   return MFCC_OK;
+}
+
+int32_t mfcc_plan_kernel(const mfcc_plan* p) {
+  if (!p) return fail(MFCC_ERR_INVALID, "mfcc_plan_kernel: null plan");
+  return p->general ? MFCC_KERNEL_GENERAL : MFCC_KERNEL_AUTO;
 }
 
 int32_t mfcc_out_width(const mfcc_plan* p, int32_t out_kind) {
@@ -475,6 +627,10 @@ static int layout_create_impl(const mfcc_plan* plan, const int64_t* lengths_host
   if (!l) return fail(MFCC_ERR_NOMEM, "mfcc_layout_create: out of host memory");
   l->device = plan->device;
   l->n_utts = n_utts;
+  l->frame_size = plan->frame_size;
+  l->frame_step = plan->frame_step;
+  l->frame_rule = plan->cfg.frame_rule;
+  l->general_cut = plan->general;
   l->sample_off.assign(n_utts + 1, 0);
   l->frame_off.assign(n_utts + 1, 0);
   std::vector<mfcc::Tile> tiles;
@@ -498,10 +654,15 @@ static int layout_create_impl(const mfcc_plan* plan, const int64_t* lengths_host
     // greedy tiling: every tile computes a whole number of 16-frame batches where it can
     // (tile frames + 4 halo frames on each side that continues)
     for (int64_t t = 0; t < nf;) {
-      const int64_t left = t > 0 ? mfcc::kHalo : 0;
       int64_t nt = nf - t;
-      if (nt + left > tile_max) nt = tile_max - left - mfcc::kHalo;
+      if (plan->general) {
+        nt = std::min<int64_t>(nt, plan->gen_nt_max);
+      } else {
+        const int64_t left = t > 0 ? mfcc::kHalo : 0;
+        if (nt + left > tile_max) nt = tile_max - left - mfcc::kHalo;
+      }
       tiles.push_back(mfcc::Tile{(int32_t)u, (int32_t)t, (int32_t)nt, 0});
+      l->max_nt = std::max<int32_t>(l->max_nt, (int32_t)nt);
       t += nt;
     }
   }
@@ -599,6 +760,10 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward: null plan or layout");
   if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
   if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_forward: the layout holds frame counts only (mfcc_layout_create_frames)");
+  {
+    const int rc_l = layout_fits(plan, layout);
+    if (rc_l) return rc_l;
+  }
   if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
   const int32_t width = mfcc_out_width(plan, out_kind);
   if (width < 0) return width;
@@ -637,6 +802,13 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
   if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: null plan or layout");
   if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
   if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: the layout holds frame counts only (mfcc_layout_create_frames)");
+  if (plan->general)
+    return fail(MFCC_ERR_UNSUPPORTED, "mfcc_forward_stacked: this plan runs the general kernel (framing %d/%d, %d-point FFT); "
+                "use mfcc_forward + mfcc_stack_context", plan->frame_size, plan->frame_step, plan->nfft);
+  {
+    const int rc_l = layout_fits(plan, layout);
+    if (rc_l) return rc_l;
+  }
   if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
   if (out_kind != MFCC_OUT_SPEC && out_kind != MFCC_OUT_LOGSPEC)
     return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: out_kind must be MFCC_OUT_SPEC or MFCC_OUT_LOGSPEC");
@@ -878,6 +1050,7 @@ int mfcc_stream_create(const mfcc_plan* plan, int32_t n_streams, int32_t max_chu
   if (max_chunk < 1 || max_chunk > (1 << 24)) return fail(MFCC_ERR_INVALID, "max_chunk=%d outside 1..2^24", max_chunk);
   if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
   if (plan->cfg.pad_fac != 2) return fail(MFCC_ERR_UNSUPPORTED, "streaming implements pad_fac=2");
+  if (plan->cfg.numcep > mfcc::kMaxCep) return fail(MFCC_ERR_UNSUPPORTED, "streaming keeps at most %d cepstra per row", mfcc::kMaxCep);
   // the emit kernel indexes (stream, row, coefficient) with 32 bits
   if ((int64_t)n_streams * (max_chunk / plan->frame_step + 2 + 2 * mfcc::kHalo) * mfcc::kMaxCep >= ((int64_t)1 << 31))
     return fail(MFCC_ERR_UNSUPPORTED, "n_streams * rows per push = %d * %d exceeds what one emit launch indexes; use fewer streams "

@@ -2,6 +2,7 @@
 // Each routine states the reference lines whose constants it reproduces.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -27,9 +28,10 @@ inline int64_t frames_for_length(int64_t n, int32_t size, int32_t step) {
 
 // Triangular mel bank [numbins][num_fft/2+1], HTK mel scale, peaks at
 // floor((num_fft+1) * hz / fs), no area normalisation.  mfcc-self5.py:102-117.
-inline std::vector<double> melbank(double fs, int numbins, double lowfreq, int num_fft) {
+// highfreq <= 0 selects the reference's fixed upper edge fs / 2 (:103).
+inline std::vector<double> melbank(double fs, int numbins, double lowfreq, int num_fft, double highfreq = 0) {
   const int nb = num_fft / 2 + 1;
-  const double highfreq = fs / 2;
+  if (!(highfreq > 0)) highfreq = fs / 2;
   const double mel_lo = 2595 * std::log10(1 + lowfreq / 700.0);
   const double mel_hi = 2595 * std::log10(1 + highfreq / 700.0);
   std::vector<double> edge(numbins + 2);
@@ -80,6 +82,18 @@ inline std::vector<double> hamming(int m) {
   if (m > 1)
     for (int n = 0; n < m; ++n) w[n] = 0.54 - 0.46 * std::cos(2 * pi * n / (m - 1));
   return w;
+}
+
+// W_n^k = exp(-2 pi i k / n), k = 0 .. n/2 - 1, interleaved (re, im) as float.
+inline std::vector<float> twiddle_half(int n) {
+  const double pi = 3.14159265358979323846;
+  std::vector<float> t((size_t)std::max(1, n / 2) * 2, 0.f);
+  for (int k = 0; k < n / 2; ++k) {
+    t[2 * k] = (float)std::cos(2 * pi * k / n);
+    t[2 * k + 1] = (float)(-std::sin(2 * pi * k / n));
+  }
+  if (n < 2) t[0] = 1.f;
+  return t;
 }
 
 // W512^m = exp(-2 pi i m / 512), m = 0..511, interleaved (re, im) as float.

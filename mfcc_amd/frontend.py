@@ -125,7 +125,7 @@ class Plan:
 
     def __init__(self, fs=16000, frame_time=25, step_time=10, num_bins=26, low_freq=0, numcep=13,
                  lift_factor=22, pad_fac=2, preemph=0.97, spectrum="power", window=None, floor_mel=False,
-                 num_fft=None, frame_rule="pad", log_floor=0.0, device=None):
+                 num_fft=None, frame_rule="pad", log_floor=0.0, high_freq=None, kernel="auto", device=None):
         self.device = _device(device)
         lib = capi.load()
         cfg = capi.MfccConfig()
@@ -147,6 +147,10 @@ class Plan:
             raise ValueError("frame_rule must be 'pad' (winfft) or 'complete' (spec_anal)")
         cfg.frame_rule = 0 if frame_rule == "pad" else 1
         cfg.log_floor = float(log_floor)
+        cfg.high_freq = 0.0 if high_freq is None else float(high_freq)   # None: fs/2 as melbanks (mfcc-self5.py:103)
+        if kernel not in ("auto", "general"):
+            raise ValueError("kernel must be 'auto' or 'general'")
+        cfg.kernel = capi.KERNEL_AUTO if kernel == "auto" else capi.KERNEL_GENERAL
         self.cfg = cfg
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -155,6 +159,8 @@ class Plan:
         v = [C.c_int32() for _ in range(5)]
         capi.check(lib.mfcc_plan_info(h, *[C.byref(x) for x in v]))
         self.frame_size, self.frame_step, self.num_fft, self.num_bins, self.numcep = [x.value for x in v]
+        # True: the general kernel runs (a framing, pad_fac or filterbank outside the specialised one)
+        self.general = capi.check(lib.mfcc_plan_kernel(h)) == capi.KERNEL_GENERAL
 
     def out_width(self, kind):
         return capi.check(capi.load().mfcc_out_width(self._h, _OUT_KINDS[kind]))
@@ -294,7 +300,7 @@ class MFCC:
 
 def mfcc39(audio, lengths=None, fs=16000, frame_time=25, step_time=10, num_bins=26, low_freq=0, numcep=13,
            lift_factor=22, pad_fac=2, preemph=0.97, spectrum="power", window=None, floor_mel=False, out=None,
-           kind="mfcc39", num_fft=None, frame_rule="pad", log_floor=0.0):
+           kind="mfcc39", num_fft=None, frame_rule="pad", log_floor=0.0, high_freq=None, kernel="auto"):
     """int16/float audio -> float32 [sum F, 39] = [c0=lnE, c1..c12 | delta | delta-delta]
     (the row layout of spectrograms(), mfcc-self5.py:181-186).  ``audio`` is one utterance
     [L], a dense batch [B, L], or a packed batch [sum L] with ``lengths``."""
@@ -302,7 +308,8 @@ def mfcc39(audio, lengths=None, fs=16000, frame_time=25, step_time=10, num_bins=
     fe.plan = get_plan(None if not isinstance(audio, torch.Tensor) or not audio.is_cuda else audio.device,
                        fs=fs, frame_time=frame_time, step_time=step_time, num_bins=num_bins, low_freq=low_freq,
                        numcep=numcep, lift_factor=lift_factor, pad_fac=pad_fac, preemph=preemph, spectrum=spectrum,
-                       window=window, floor_mel=floor_mel, num_fft=num_fft, frame_rule=frame_rule, log_floor=log_floor)
+                       window=window, floor_mel=floor_mel, num_fft=num_fft, frame_rule=frame_rule, log_floor=log_floor,
+                       high_freq=high_freq, kernel=kernel)
     fe._layouts = _layout_cache.setdefault(id(fe.plan), {})
     return fe(audio, lengths, out=out, kind=kind)
 
@@ -330,7 +337,7 @@ def spectrum_stack(fe, audio, layout, framenum, out=None, log=True):
     framenum = int(framenum)
     width = fe.plan.out_width("spec")
     shape = (layout.total_frames, framenum * width)
-    if framenum % 4 != 1 or framenum > 65:
+    if framenum % 4 != 1 or framenum > 65 or fe.plan.general:
         spec = fe.forward(audio, layout, kind="logspec" if log else "spec")
         return stack_context(spec, framenum, frame_counts=np.diff(layout.frame_offsets), out=out)
     if out is None:

@@ -1,0 +1,195 @@
+"""GPU parity of the general-geometry kernel: every (fs, frame_time, step_time) the reference's
+winfft accepts (mfcc-self5.py:75-84), any pad_fac of delta (:169), other filterbank / cepstrum
+sizes.  Checked against golden vectors the reference's own functions produced at 8 kHz
+(200/80 samples, 256-point FFT), 44.1 kHz (1102/441, 2048-point), 20 ms frames (320/160, 512-point)
+and 32 ms / 8 ms (512/128, 512-point), and against the CPU oracle.  Tolerances as in
+test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mfcc_oracle as O
+from test_gpu_parity import VARIANTS, assert_cep, assert_logmel, _stream_all
+
+pytestmark = pytest.mark.gpu
+
+GEOMS = ("8k", "44k", "16k_20ms", "16k_32ms_8ms")
+
+
+@pytest.fixture(scope="module")
+def M():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import mfcc_amd
+    return mfcc_amd
+
+
+def _synth(seed, n):
+    rng = np.random.default_rng(seed)
+    return np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("gname", GEOMS)
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_other_frame_geometries_against_reference_goldens(M, golden, gname, variant):
+    """One ragged batch per geometry holding every golden utterance; each utterance's rows against
+    what the reference's own pipeline produced for it."""
+    g = golden("geometry.npz")
+    fs, frame_time, step_time = (float(v) for v in g[f"{gname}_cfg"])
+    lengths = [int(v) for v in g[f"{gname}_lengths"]]
+    audios = [g[f"{gname}_audio_{n}"] for n in lengths]
+    fe = M.MFCC(variant, fs=fs, frame_time=frame_time, step_time=step_time)
+    size, step, nfft = O.frame_geometry(fs, frame_time, step_time)
+    assert (fe.plan.frame_size, fe.plan.frame_step, fe.plan.num_fft) == (size, step, nfft) and nfft == int(g[f"{gname}_nfft"])
+    assert fe.plan.general
+    packed = torch.from_numpy(np.concatenate(audios)).cuda()
+    lay = fe.layout(lengths)
+    out = fe.forward(packed, lay).cpu().numpy()
+    lm = fe.forward(packed, lay, kind="logmel").cpu().numpy()
+    st = fe.forward(packed, lay, kind="static").cpu().numpy()
+    spec = fe.forward(packed, lay, kind="spec").cpu().numpy()
+    assert spec.shape[1] == nfft // 2 + 1
+    for u, n in enumerate(lengths):
+        a, b = lay.frame_offsets[u], lay.frame_offsets[u + 1]
+        ref = g[f"{gname}_{variant}_out_{n}"]
+        assert b - a == ref.shape[0] == O.frame_count(n, size, step)
+        assert_cep(out[a:b], ref, f"{gname} {variant} L={n}")
+        assert_cep(st[a:b], ref[:, :13], f"{gname} {variant} static L={n}")
+        assert_logmel(lm[a:b, :26], g[f"{gname}_{variant}_logmel_{n}"], f"{gname} {variant} ln-mel L={n}")
+        assert_logmel(lm[a:b, 26], g[f"{gname}_{variant}_loge_{n}"], f"{gname} {variant} ln-E L={n}")
+        key = f"{gname}_{variant}_spec_{n}"
+        if key in g.files:
+            sref = g[key]
+            assert (np.abs(spec[a:b] - sref) <= 2e-6 * np.abs(sref).max(axis=1, keepdims=True)).all()
+    # float32 samples take the same path
+    outf = fe(packed.to(torch.float32), lengths=lengths).cpu().numpy()
+    assert_cep(outf, out, f"{gname} float input", atol=2e-3 if variant == "self5" else 1e-3)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_general_kernel_at_the_default_framing(M, golden, variant):
+    """kernel='general' at 400/160/512: the reference's own utterance and the frame-count edge
+    cases through the general kernel, against the goldens and against the specialised kernel."""
+    g = golden("ldc93s1.npz")
+    fe = M.MFCC(variant, kernel="general")
+    fast = M.MFCC(variant)
+    assert fe.plan.general and not fast.plan.general
+    audio = torch.from_numpy(g["audio"]).cuda()
+    out = fe(audio).cpu().numpy()
+    assert_cep(out, g[f"{variant}_out"], f"general {variant} out")
+    assert_cep(out, fast(audio).cpu().numpy(), "general vs specialised", atol=2e-3)
+    lm = fe(audio, kind="logmel").cpu().numpy()
+    assert_logmel(lm[:, :26], g[f"{variant}_logmel"], f"general {variant} ln-mel")
+    assert_logmel(lm[:, 26], g[f"{variant}_loge"], f"general {variant} ln-energy")
+    s = golden("synthetic.npz")
+    lengths = [int(v) for v in s["lengths"]]
+    got = fe(np.concatenate([s[f"audio_{n}"] for n in lengths]), lengths=lengths)
+    pos = 0
+    for n in lengths:
+        ref = s[f"{variant}_out_{n}"]
+        assert_cep(got[pos:pos + ref.shape[0]], ref, f"general {variant} L={n}")
+        pos += ref.shape[0]
+    assert pos == got.shape[0]
+    # digital silence: -inf ln-mel, NaN cepstra, floored energy -- the reference's pattern
+    sp = golden("special.npz")
+    for name in ("zeros", "tailzeros", "dc", "fullscale"):
+        assert_cep(fe(sp[f"audio_{name}"]), sp[f"{variant}_out_{name}"], f"general {variant} {name}")
+        lmz = fe(sp[f"audio_{name}"], kind="logmel")
+        assert_logmel(lmz[:, :26], sp[f"{variant}_logmel_{name}"], f"general {variant} {name} ln-mel")
+
+
+@pytest.mark.parametrize("pad_fac", [1, 3, 5])
+def test_fused_delta_with_other_pad_fac(M, golden, pad_fac):
+    """delta(features, pad_fac) is general in the reference (mfcc-self5.py:169-179; the pad_fac=3
+    golden of the stage test pins the oracle): whole rows [c | d | dd] with that regression width,
+    over a ragged batch with utterances shorter than the window and longer than a tile."""
+    s = golden("stages.npz")
+    np.testing.assert_allclose(O.delta(s["delta_in"], 3), s["delta_out_pad3"], rtol=0, atol=1e-12)
+    lengths = [1, 400, 561, 1300, 48000, 120000]
+    audios = [_synth(50 + i, n) for i, n in enumerate(lengths)]
+    fe = M.MFCC("self5", pad_fac=pad_fac)
+    assert fe.plan.general
+    got = fe(np.concatenate(audios), lengths=lengths)
+    pos = 0
+    for a in audios:
+        static = O.mfcc39(a, "self5", loop=False, return_stages=True)["static"]
+        d = O.delta(static, pad_fac, loop=False)
+        ref = O.spectrograms(static, d, O.delta(d, pad_fac, loop=False))
+        assert_cep(got[pos:pos + ref.shape[0]], ref, f"pad_fac={pad_fac} L={len(a)}")
+        pos += ref.shape[0]
+    assert pos == got.shape[0]
+
+
+def test_other_filterbank_and_cepstrum_sizes(M):
+    """64 filters / 20 cepstra / low_freq 100 (outside the specialised kernel's 40 / 16): against
+    the oracle's stage functions."""
+    a = _synth(77, 20000)
+    fe = M.MFCC("self5", num_bins=64, numcep=20, low_freq=100, lift_factor=0)
+    assert fe.plan.general
+    got = fe(a)
+    _mag, pw, _w, nfft = O.winfft(O.preemphasis(a), loop=False)
+    logmel, loge = O.melspec(pw, O.melbanks(16000, 64, 100, nfft), loop=False)
+    static = O.staticfeatures(loge, O.dctopt(O.dct_ortho(logmel, 20, loop=False), 0))
+    d = O.delta(static, loop=False)
+    assert_cep(got, O.spectrograms(static, d, O.delta(d, loop=False)), "64 filters, 20 cepstra")
+    assert_logmel(fe(a, kind="logmel")[:, :64], logmel, "64 filters ln-mel")
+
+
+def test_explicit_fft_length_shorter_than_the_frame(M):
+    """np.fft.rfft(chunk, n) with n < len(chunk) uses the first n samples (the call at
+    mfcc-self5.py:96 with another num_fft): 400-sample frames, 256-point FFT."""
+    a = _synth(78, 5000)
+    fe = M.MFCC("self15", num_fft=256)
+    assert fe.plan.general and fe.plan.num_fft == 256
+    assert_cep(fe(a), O.mfcc39(a, "self15", num_fft=256, loop=False), "num_fft=256 < frame")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_reference_named_winfft_at_other_rates(M, golden, variant):
+    """winfft(audio, fs, frame_time, step_time) keeps the reference's signature for any rate: the
+    returned spectra, window and num_fft at 8 kHz, 44.1 kHz and 20 ms frames."""
+    g = golden("geometry.npz")
+    for gname in ("8k", "44k", "16k_20ms"):
+        fs, frame_time, step_time = (float(v) for v in g[f"{gname}_cfg"])
+        n = int(g[f"{gname}_lengths"][1])
+        audio = g[f"{gname}_audio_{n}"]
+        src = O.preemphasis(audio).astype(np.float32) if variant == "self5" else audio
+        mag, pw, win, nfft = M.winfft(src, fs, frame_time, step_time)
+        assert nfft == int(g[f"{gname}_nfft"]) and win.shape == (O.frame_geometry(fs, frame_time, step_time)[0],)
+        sref = g[f"{gname}_{variant}_spec_{n}"]
+        got = pw if variant == "self5" else mag
+        assert (np.abs(got - sref) <= 4e-6 * np.abs(sref).max(axis=1, keepdims=True)).all()
+
+
+def test_streaming_at_8khz_with_the_derived_256_point_fft(M):
+    """StreamingMFCC on a general plan: pushes + flush equal the offline rows."""
+    a = _synth(79, 12345)
+    for variant in VARIANTS:
+        s = M.StreamingMFCC(variant, n_streams=2, max_chunk=400, fs=8000)
+        assert s.plan.general and s.plan.num_fft == 256
+        both = torch.from_numpy(np.stack([a, a[::-1].copy()])).cuda()
+        got = _stream_all(s, both, [80, 333, 7]).cpu().numpy()
+        assert_cep(got[0], O.mfcc39(a, variant, fs=8000, loop=False), f"8 kHz stream {variant}")
+        assert_cep(got[1], O.mfcc39(a[::-1], variant, fs=8000, loop=False), f"8 kHz stream {variant} (2)")
+
+
+def test_layouts_and_plans_of_different_framings_do_not_mix(M):
+    """A layout's tiles are cut for its plan's framing: another framing is refused, not run."""
+    a = torch.from_numpy(_synth(80, 30000)).cuda()
+    fe16, fe8 = M.MFCC("self5"), M.MFCC("self5", fs=8000)
+    with pytest.raises(M.frontend.capi.MfccError):
+        fe8.forward(a, fe16.layout([30000]))
+    with pytest.raises(M.frontend.capi.MfccError):
+        fe16.forward(a, fe8.layout([30000]))
+    # same framing, other kernel: the general kernel's short tiles suit the specialised kernel
+    gen = M.MFCC("self5", kernel="general")
+    assert_cep(fe16.forward(a, gen.layout([30000])).cpu().numpy(), fe16(a).cpu().numpy(), "general-cut layout", atol=0)
+    # ... but not the other way round when a tile is longer than the general kernel holds
+    with pytest.raises(M.frontend.capi.MfccError):
+        gen.forward(a, fe16.layout([30000]))
+    # configurations no kernel covers still say so
+    with pytest.raises(M.frontend.capi.MfccError):
+        M.MFCC("self5", fs=192000)            # 4800-sample frames: 8192-point FFT
+    with pytest.raises(M.frontend.capi.MfccError):
+        M.MFCC("self5", num_fft=500)          # not a power of two
+    with pytest.raises(M.frontend.capi.MfccError):
+        M.MFCC("self5", fs=30)                # int(30 * 0.010) = 0 samples per step

@@ -70,10 +70,14 @@ def test_argument_errors_without_gpu(lib):
     assert lib.mfcc_plan_create(None, 0, None) == capi.ERR_INVALID
     cfg = capi.MfccConfig()
     lib.mfcc_config_default(C.byref(cfg))
-    cfg.fs = 8000.0
+    cfg.fs = 192000.0   # 4800-sample frames would need an 8192-point FFT: refused before any device call
     h = C.c_void_p()
     assert lib.mfcc_plan_create(C.byref(cfg), 0, C.byref(h)) == capi.ERR_UNSUPPORTED
-    assert b"400/160/512" in lib.mfcc_last_error()
+    assert b"FFT lengths" in lib.mfcc_last_error()
+    cfg.fs, cfg.pad_fac = 16000.0, 0
+    assert lib.mfcc_plan_create(C.byref(cfg), 0, C.byref(h)) == capi.ERR_UNSUPPORTED
+    cfg.pad_fac, cfg.kernel = 2, 7
+    assert lib.mfcc_plan_create(C.byref(cfg), 0, C.byref(h)) == capi.ERR_INVALID
     assert lib.mfcc_forward(None, None, None, 0, None, 39, 0, None) == capi.ERR_INVALID
     assert lib.mfcc_delta(None, -1, 13, 2, None, None) == capi.ERR_INVALID
 
