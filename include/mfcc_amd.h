@@ -89,6 +89,9 @@ typedef struct mfcc_config {
   double high_freq;   /* 0 = fs/2, the upper edge melbanks always uses (mfcc-self5.py:103); otherwise the
                          upper edge in Hz (the highfreq argument of the CTC scripts' MFCC routine) */
   int32_t kernel;     /* MFCC_KERNEL_*                                             */
+  int32_t keep_c0;    /* 0 = coefficient 0 is replaced by ln E as staticfeatures does (mfcc-self5.py:164);
+                         1 = keep the DCT's own c0 (appendEnergy=False of the CTC scripts' MFCC routine;
+                             runs the general kernel)                                          */
 } mfcc_config;
 
 typedef struct mfcc_plan mfcc_plan;     /* immutable constant tables on one device          */

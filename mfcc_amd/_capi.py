@@ -43,6 +43,7 @@ class MfccConfig(C.Structure):
         ("log_floor", C.c_double),
         ("high_freq", C.c_double),
         ("kernel", C.c_int32),
+        ("keep_c0", C.c_int32),
     ]
 
 

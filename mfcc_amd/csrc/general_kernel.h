@@ -43,6 +43,7 @@ struct GeneralConst {
   int32_t used;           // samples of a frame that enter the FFT = min(frame_size, nfft) (np.fft.rfft truncates)
   int32_t nmel, numcep, pad_fac;
   int32_t spectrum, floor_mel;
+  int32_t keep_c0;        // 1: coefficient 0 stays the DCT's own value instead of ln E
   float pre_hi, pre_lo;   // 0, 0 = no pre-emphasis
   float inv_nfft;         // power spectrum scale 1/nfft (mfcc-self5.py:97)
   float log_floor;
@@ -78,7 +79,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const GeneralConst* __restrict__ gcp, int out_kind) {
   extern __shared__ __attribute__((aligned(16))) float gsm[];
   const GeneralConst gc = *gcp;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = gc.nfft >> 1, nbin = M + 1;
   const int nmel = gc.nmel, ncep = gc.numcep, pf = gc.pad_fac;
   float* const wbase = gsm + wave * general_wave_floats(gc.nfft, nmel);
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
     for (int c = lane; c < ncep; c += 64) {
       float acc = 0.f;
       for (int n = 0; n < nmel; ++n) acc = fmaf(lrow[n], gc.dctl[n * ncep + c], acc);
-      if (c == 0) acc = lne;
+      if (c == 0 && !gc.keep_c0) acc = lne;
       if (full) stat[(t - s_lo) * ncep + c] = acc;
       else if (own) p.out[(f_off + t) * ld + c] = acc;
     }

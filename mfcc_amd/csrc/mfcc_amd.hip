@@ -291,6 +291,7 @@ void mfcc_config_default(mfcc_config* cfg) {
   cfg->log_floor = 0.0;
   cfg->high_freq = 0.0;
   cfg->kernel = MFCC_KERNEL_AUTO;
+  cfg->keep_c0 = 0;
 }
 
 int mfcc_melbank_host(double fs, int32_t numbins, double lowfreq, int32_t num_fft, double* out_host) {
@@ -493,6 +494,7 @@ static int build_general(mfcc_plan* p) {
   int denom = 0;
   for (int i = 1; i <= pf; ++i) denom += 2 * i * i;  // mfcc-self5.py:172
   g.delta_denom = (float)denom;
+  g.keep_c0 = cfg->keep_c0 ? 1 : 0;
   g.stat_rows = rows;
   if ((rc = upload(std::vector<mfcc::GeneralConst>(1, g), &p->gc))) return rc;
   p->general = true;
@@ -555,7 +557,7 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   const bool g16k = size == mfcc::Geom16k::kSize && step == mfcc::Geom16k::kStep;
   const bool g8k = size == mfcc::Geom8k::kSize && step == mfcc::Geom8k::kStep;
   bool specialised = cfg->kernel == MFCC_KERNEL_AUTO && (g16k || g8k) && nfft == mfcc::kNfft && cfg->num_bins <= mfcc::kMaxMel &&
-                     cfg->numcep <= mfcc::kMaxCep && cfg->pad_fac == 2;
+                     cfg->numcep <= mfcc::kMaxCep && cfg->pad_fac == 2 && !cfg->keep_c0;
   int rc = MFCC_OK;
   try {
     if (specialised) {

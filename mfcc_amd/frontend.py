@@ -125,7 +125,7 @@ class Plan:
 
     def __init__(self, fs=16000, frame_time=25, step_time=10, num_bins=26, low_freq=0, numcep=13,
                  lift_factor=22, pad_fac=2, preemph=0.97, spectrum="power", window=None, floor_mel=False,
-                 num_fft=None, frame_rule="pad", log_floor=0.0, high_freq=None, kernel="auto", device=None):
+                 num_fft=None, frame_rule="pad", log_floor=0.0, high_freq=None, kernel="auto", keep_c0=False, device=None):
         self.device = _device(device)
         lib = capi.load()
         cfg = capi.MfccConfig()
@@ -151,6 +151,7 @@ class Plan:
         if kernel not in ("auto", "general"):
             raise ValueError("kernel must be 'auto' or 'general'")
         cfg.kernel = capi.KERNEL_AUTO if kernel == "auto" else capi.KERNEL_GENERAL
+        cfg.keep_c0 = 1 if keep_c0 else 0
         self.cfg = cfg
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -300,7 +301,7 @@ class MFCC:
 
 def mfcc39(audio, lengths=None, fs=16000, frame_time=25, step_time=10, num_bins=26, low_freq=0, numcep=13,
            lift_factor=22, pad_fac=2, preemph=0.97, spectrum="power", window=None, floor_mel=False, out=None,
-           kind="mfcc39", num_fft=None, frame_rule="pad", log_floor=0.0, high_freq=None, kernel="auto"):
+           kind="mfcc39", num_fft=None, frame_rule="pad", log_floor=0.0, high_freq=None, kernel="auto", keep_c0=False):
     """int16/float audio -> float32 [sum F, 39] = [c0=lnE, c1..c12 | delta | delta-delta]
     (the row layout of spectrograms(), mfcc-self5.py:181-186).  ``audio`` is one utterance
     [L], a dense batch [B, L], or a packed batch [sum L] with ``lengths``."""
@@ -309,7 +310,7 @@ def mfcc39(audio, lengths=None, fs=16000, frame_time=25, step_time=10, num_bins=
                        fs=fs, frame_time=frame_time, step_time=step_time, num_bins=num_bins, low_freq=low_freq,
                        numcep=numcep, lift_factor=lift_factor, pad_fac=pad_fac, preemph=preemph, spectrum=spectrum,
                        window=window, floor_mel=floor_mel, num_fft=num_fft, frame_rule=frame_rule, log_floor=log_floor,
-                       high_freq=high_freq, kernel=kernel)
+                       high_freq=high_freq, kernel=kernel, keep_c0=keep_c0)
     fe._layouts = _layout_cache.setdefault(id(fe.plan), {})
     return fe(audio, lengths, out=out, kind=kind)
 

@@ -11,8 +11,11 @@ The package itself is not available to check against, so parity with it is UNPIN
 checked is the documented algorithm, which is the numpy routine of mfcc-self5.py with two
 differences: mel energies that are exactly zero are floored to eps before the log (the numpy
 routine discards that floor, mfcc-self5.py:126-127), and ``appendEnergy=False`` keeps the DCT's
-own c0.  Supported geometry is what the gfx950 kernels are built for: 25 ms / 10 ms frames at
-16 kHz or at 8 kHz (RATE = 8000 in inference_ctc_eri_05.py:96), nfft 512, highfreq = samplerate / 2.
+own c0.  Frame sizes are int(winlen * samplerate) as the reference's winfft takes them
+(mfcc-self5.py:75-76; the package rounds half up, which differs only when winlen * samplerate has a
+fractional part of .5 or more).  25 ms / 10 ms frames at 16 kHz or 8 kHz (RATE = 8000 in
+inference_ctc_eri_05.py:96) with nfft 512 run the specialised kernel; every other framing, FFT
+length (a power of two), highfreq, or appendEnergy=False runs the general one.
 """
 from __future__ import annotations
 
@@ -26,25 +29,28 @@ def mfcc(signal, samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=
          highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True, winfunc=None):
     """[L] samples -> [F, numcep] float32 cepstra (c0 replaced by ln of the frame energy when
     ``appendEnergy``)."""
-    if highfreq is not None and float(highfreq) != samplerate / 2:
-        raise ValueError("highfreq must be None or samplerate/2 (the filterbank ends at the Nyquist frequency)")
-    if nfft != 512:
-        raise ValueError("nfft must be 512")
+    size = int(samplerate * (winlen * 1000 * (1.0 / 1000)))
+    window = None
     if winfunc is not None:
-        raise ValueError("winfunc: only the package default (rectangular window) is implemented")
-    if not appendEnergy:
-        raise ValueError("appendEnergy=False is not implemented (c0 is always ln of the frame energy)")
+        w = np.asarray(winfunc(size), dtype=np.float64)
+        if w.shape != (size,):
+            raise ValueError("winfunc(frame_length) must return frame_length weights")
+        if np.array_equal(w, np.hamming(size)):
+            window = "hamming"
+        elif not np.array_equal(w, np.ones(size)):
+            raise ValueError("winfunc: the rectangular window (package default) and numpy.hamming are implemented")
     return F.mfcc39(signal, fs=samplerate, frame_time=winlen * 1000, step_time=winstep * 1000, num_bins=nfilt,
-                    low_freq=lowfreq, numcep=numcep, lift_factor=ceplifter, preemph=preemph if preemph else None,
-                    spectrum="power", floor_mel=True, kind="static", num_fft=nfft)
+                    low_freq=lowfreq, high_freq=highfreq, numcep=numcep, lift_factor=ceplifter,
+                    preemph=preemph if preemph else None, spectrum="power", floor_mel=True, kind="static",
+                    num_fft=nfft, window=window, keep_c0=not appendEnergy)
 
 
 def delta(feat, N):
-    """Regression over +-N frames with edge replication; N = 2 is implemented (every call site of
-    the reference uses 2)."""
-    if N != 2:
-        raise ValueError("delta: N=2 is implemented")
-    return F.delta(feat, N)
+    """Regression over +-N frames with edge replication (the delta of mfcc-self5.py:169-179 with
+    pad_fac = N)."""
+    if N < 1:
+        raise ValueError("N must be an integer >= 1")
+    return F.delta(feat, int(N))
 
 
 def get_wav_mfcc(audio, fs=16000):

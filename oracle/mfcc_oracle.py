@@ -111,9 +111,11 @@ def winfft(audio, fs=FS, frame_time=FRAME_TIME, step_time=STEP_TIME, loop=True, 
     return mag, pw, win, nfft
 
 
-def mel_bin_edges(fs=FS, numbins=NUM_BINS, lowfreq=LOW_FREQ, num_fft=512):
-    """FFT-bin positions of the numbins+2 mel peaks (self5:104-109)."""
-    highfreq = fs / 2
+def mel_bin_edges(fs=FS, numbins=NUM_BINS, lowfreq=LOW_FREQ, num_fft=512, highfreq=None):
+    """FFT-bin positions of the numbins+2 mel peaks (self5:104-109).  The reference fixes the upper
+    edge at fs/2 (:103); ``highfreq`` is the argument of the CTC scripts' MFCC routine
+    (inference_ctc_eri_05.py:253-257), not part of the reference's melbanks."""
+    highfreq = fs / 2 if highfreq is None else highfreq
     mel_lo = 2595 * np.log10(1 + lowfreq / 700.0)
     mel_hi = 2595 * np.log10(1 + highfreq / 700.0)
     mel_pts = np.linspace(mel_lo, mel_hi, numbins + 2)
@@ -121,13 +123,13 @@ def mel_bin_edges(fs=FS, numbins=NUM_BINS, lowfreq=LOW_FREQ, num_fft=512):
     return np.floor((num_fft + 1) * hz / fs)
 
 
-def melbanks(fs=FS, numbins=NUM_BINS, lowfreq=LOW_FREQ, num_fft=512):
+def melbanks(fs=FS, numbins=NUM_BINS, lowfreq=LOW_FREQ, num_fft=512, highfreq=None):
     """Triangular mel filterbank [numbins, num_fft//2+1]  (self5:102-117).
 
     Rising edge (i-b_j)/(b_{j+1}-b_j) on [b_j, b_{j+1}); falling edge
     (b_{j+2}-i)/(b_{j+2}-b_{j+1}) on [b_{j+1}, b_{j+2}); no normalisation.
     """
-    edges = mel_bin_edges(fs, numbins, lowfreq, num_fft)
+    edges = mel_bin_edges(fs, numbins, lowfreq, num_fft, highfreq)
     bank = np.zeros((numbins, num_fft // 2 + 1))
     for j in range(numbins):
         lo, mid, hi = edges[j], edges[j + 1], edges[j + 2]

@@ -204,9 +204,29 @@ def test_full_size_batch_properties(M):
     assert torch.isfinite(out).all()
     sub = fe(audio[4321:4325].contiguous())
     assert torch.equal(sub, out[4321 * 299:4325 * 299])
-    for u in (0, 777, 9999):
+    for u in list(range(0, 10000, 769)) + [9999]:       # a strided sample of 15 utterances
         ref = O.mfcc39(audio[u].cpu().numpy(), "self5", loop=False)
         assert_cep(out[u * 299:(u + 1) * 299].cpu().numpy(), ref, f"utt {u}")
+    # the delta columns of EVERY row are the regression of the static columns of its own utterance
+    st = out[:, :13].reshape(10000, 299, 13)
+    idx = torch.arange(299, device="cuda")
+    def reg(x):
+        tap = lambda k: x[:, torch.clamp(idx + k, 0, 298)]
+        return (2 * (tap(2) - tap(-2)) + (tap(1) - tap(-1))) / 10
+    d = reg(st)
+    assert (out[:, 13:26].reshape(10000, 299, 13) - d).abs().max() < 1e-4
+    assert (out[:, 26:].reshape(10000, 299, 13) - reg(d)).abs().max() < 1e-4
+
+
+def test_loadrawdata_round_trip(M, golden, tmp_path):
+    """loadrawdata (mfcc-self5.py:32-36): a headerless little-endian int16 file comes back sample
+    for sample and feeds the pipeline like the array it was written from."""
+    g = golden("ldc93s1.npz")
+    path = tmp_path / "utt.raw"
+    g["audio"].astype("<i2").tofile(str(path))
+    raw = M.loadrawdata(str(path))
+    assert raw.dtype == np.int16 and np.array_equal(raw, g["audio"])
+    assert_cep(M.mfcc39(raw), g["self5_out"], "loadrawdata -> mfcc39")
 
 
 # ----------------------------------------------------------------------------------------
@@ -358,6 +378,22 @@ def _stream_all(s, audio, chunks):
         i += 1
     parts.append(s.flush())
     return torch.cat(parts, dim=1)
+
+
+@pytest.mark.gpu
+def test_streaming_64_streams_of_10ms_hops():
+    """The largest streaming batch of the BASELINE configuration: 64 lock-step streams pushed in
+    10 ms hops; every stream equals the offline rows of its own audio and the oracle."""
+    import mfcc_amd
+    rng = np.random.default_rng(64)
+    B, L = 64, 3200 + 57
+    audio = np.clip(rng.standard_normal((B, L)) * 3000, -32768, 32767).astype(np.int16)
+    s = mfcc_amd.StreamingMFCC("self5", n_streams=B, max_chunk=160)
+    got = _stream_all(s, torch.from_numpy(audio).cuda(), [160]).cpu().numpy()
+    off = mfcc_amd.MFCC("self5")(torch.from_numpy(audio).cuda()).cpu().numpy().reshape(B, -1, 39)
+    np.testing.assert_allclose(got, off, rtol=0, atol=2e-5)
+    for b in (0, 17, 63):
+        assert_cep(got[b], O.mfcc39(audio[b], "self5", loop=False), f"stream {b} of 64")
 
 
 @pytest.mark.gpu
@@ -529,8 +565,24 @@ def test_psf_style_call_matches_documented_algorithm():
     np.testing.assert_allclose(d, O.delta(feat.astype(np.float64), loop=False), rtol=0, atol=1e-4)
     full = psf.get_wav_mfcc(audio, 16000)
     assert full.shape == (feat.shape[0], 39) and np.allclose(full[:, :13], feat, atol=1e-6)
+    # the other arguments of that call signature (general kernel): upper band edge, FFT length,
+    # window function, the DCT's own c0, regression width
+    _mag, pw, _w, _n = O.winfft(O.preemphasis(audio), loop=False, num_fft=1024)
+    win = np.hamming(400)
+    idx = np.arange(pw.shape[0])[:, None] * 160 + np.arange(400)[None, :]
+    padded = np.zeros(idx.max() + 1)
+    padded[:len(audio)] = O.preemphasis(audio)
+    pw = np.square(np.abs(np.fft.rfft(padded[idx] * win, 1024, axis=1))) / 1024
+    mel = pw @ O.melbanks(16000, 20, 100, 1024, highfreq=4000).T
+    lm = np.log(np.where(mel == 0, O.EPS64, mel))
+    ref = O.dctopt(O.dct_ortho(lm, 12, loop=False), 22)      # appendEnergy=False: c0 stays the DCT's
+    feat = psf.mfcc(audio, nfft=1024, nfilt=20, numcep=12, lowfreq=100, highfreq=4000, appendEnergy=False, winfunc=np.hamming)
+    assert_cep(feat, ref, "psf.mfcc(nfft=1024, highfreq=4000, appendEnergy=False, winfunc=np.hamming)")
+    np.testing.assert_allclose(psf.delta(feat, 3), O.delta(feat.astype(np.float64), 3, loop=False), rtol=0, atol=1e-4)
     with pytest.raises(ValueError):
-        psf.mfcc(audio, highfreq=4000)
+        psf.mfcc(audio, winfunc=np.blackman)
+    with pytest.raises(Exception):
+        psf.mfcc(audio, highfreq=9000)
 
 
 @pytest.mark.gpu
