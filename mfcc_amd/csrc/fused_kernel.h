@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const gfloat_ptr window = as_global(pc->window);
   // this wave's share of the filterbank product
   const int mel_k0 = pc->map.kstart[wave], mel_nf = pc->map.nfilt[wave], mel_ff = pc->map.first_filter[wave];
+  const bool mel_long = pc->mel_steps[wave] > kMelSteps - 4;  // wave-uniform
   typedef const f32x4 __attribute__((address_space(1))) * gfloat4_ptr;
   const gfloat4_ptr melB4 = (gfloat4_ptr)(uintptr_t)pc->melB + (wave * (kMelSteps / 4)) * 64 + lane;
   static_assert(kMelSteps % 4 == 0, "filterbank operands are fetched four k-steps at a time");
@@ -744,9 +745,18 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // then holds filter slots 4 g4 + r of frame q, which is exactly the B-operand layout of a
       // following product that sums over the filter slots -- the DCT needs no trip through LDS.
 #pragma unroll
-      for (int s = 0; s < kMelSteps; s += 2) {
+      for (int s = 0; s < kMelSteps - 4; s += 2) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], pa[s], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s + 1], pa[s + 1], acc2, 0, 0, 0);
+      }
+      // the last four k-steps only where this wave's bin range reaches them (the matrix
+      // instructions share the vector ALU's issue time: a k-step of zero weights is not free)
+      if (mel_long) {
+#pragma unroll
+        for (int s = kMelSteps - 4; s < kMelSteps; s += 2) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], pa[s], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s + 1], pa[s + 1], acc2, 0, 0, 0);
+        }
       }
       acc += acc2;
 #else
@@ -755,12 +765,16 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // slots below mel_nf are this wave's filters: ln at once (mfcc-self5.py:125-127, unfloored by
       // default: ln 0 = -inf); slot 15 is this wave's share of the frame's energy sum
       float lm[4];
+      f32x4 mv = acc;  // acc[3] of lane group 3 stays the unfloored energy partial
+      if (floor_mel) {
+        // a real branch on the wave-uniform flag (written as a select, the compare and the select
+        // would run in the unfloored default too)
+        asm volatile("" ::: "memory");
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[r];
-        if (floor_mel && v == 0.f) v = kEps64;  // wave-uniform flag: the unfloored default pays nothing
-        lm[r] = 4 * g4 + r < mel_nf ? fast_ln(v) : 0.f;
+        for (int r = 0; r < 4; ++r) mv[r] = mv[r] == 0.f ? kEps64 : mv[r];
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lm[r] = 4 * g4 + r < mel_nf ? fast_ln(mv[r]) : 0.f;
       float* const tile_w = part + wave * kPartTile;
       if (g4 == 3) tile_w[((q >> 2) * kPartSlots + 16) * 4 + (q & 3)] = acc[3];
       if (OUT == kOutLogmel) {

@@ -376,7 +376,7 @@ static int build_specialised(mfcc_plan* p) {
     static_assert((mfcc::kRowPad - 4 * mfcc::kMelSteps) % 4 == 0, "clamped start stays 16-byte aligned");
     pmap.first_filter[g] = best_cut[g];
     pmap.nfilt[g] = best_cut[g + 1] - best_cut[g];
-    pch.mel_steps[g] = best_steps[g];
+    pch.mel_steps[g] = 0;  // set below: one past the last k-step that carries a weight
     for (int sidx = 0; sidx < mfcc::kMelSteps; ++sidx)
       for (int lane = 0; lane < 64; ++lane) {
         // k-step sidx of lane group (lane >> 4) takes bin kstart + 16 (sidx / 4) + 4 (lane >> 4) + sidx % 4
@@ -388,6 +388,7 @@ static int build_specialised(mfcc_plan* p) {
         }
         // four consecutive k-steps of a lane are 16 contiguous bytes: [wave][step/4][lane][step%4]
         melB[(((size_t)g * (mfcc::kMelSteps / 4) + sidx / 4) * 64 + lane) * 4 + sidx % 4] = (float)(w * (double)p->spec_scale);
+        if (w != 0.0) pch.mel_steps[g] = std::max(pch.mel_steps[g], sidx + 1);
       }
   }
   pmap.ndct = (nmel + 3) / 4;
