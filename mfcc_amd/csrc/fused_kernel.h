@@ -127,7 +127,7 @@ struct PlanConst {
   const float* tw512;     // [512][2]  exp(-2 pi i m / 512)
   const float* melB;      // [4][kMelSteps/4][64][4] B operands (filter weights * spec_scale): 16 B per lane and 4 k-steps
   const float* dctA;      // [4 waves][64][4] per-wave DCT*lifter weights of the chained product: lane (c = lane & 15,
-                          //   g = lane >> 4), element r = weight of (filter first_filter[w] + 4 g + r, coefficient c)
+                          //   g = lane >> 4), element r = weight of (filter first_filter[w] + g + 4 r, coefficient c)
   const float* window;    // [512] or nullptr
   MelMap map;
   int32_t mel_steps[4];   // k-steps wave w really needs (<= kMelSteps)
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const gfloat_ptr window = as_global(pc->window);
   // this wave's share of the filterbank product
   const int mel_k0 = pc->map.kstart[wave], mel_nf = pc->map.nfilt[wave], mel_ff = pc->map.first_filter[wave];
-  const bool mel_long = pc->mel_steps[wave] > kMelSteps - 4;  // wave-uniform
+  const int mel_groups = (pc->mel_steps[wave] + 3) >> 2;  // groups of four k-steps this wave needs (wave-uniform)
   typedef const f32x4 __attribute__((address_space(1))) * gfloat4_ptr;
   const gfloat4_ptr melB4 = (gfloat4_ptr)(uintptr_t)pc->melB + (wave * (kMelSteps / 4)) * 64 + lane;
   static_assert(kMelSteps % 4 == 0, "filterbank operands are fetched four k-steps at a time");
@@ -742,22 +742,24 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         pa[s] = v.x; pa[s + 1] = v.y; pa[s + 2] = v.z; pa[s + 3] = v.w;
       }
       // The product is formed transposed, D[filter slot][frame] (weights as the A operand): a lane
-      // then holds filter slots 4 g4 + r of frame q, which is exactly the B-operand layout of a
+      // then holds filter slots g4 + 4 r of frame q, which is exactly the B-operand layout of a
       // following product that sums over the filter slots -- the DCT needs no trip through LDS.
 #pragma unroll
-      for (int s = 0; s < kMelSteps - 4; s += 2) {
+      for (int s = 0; s < kMelSteps - 8; s += 2) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], pa[s], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s + 1], pa[s + 1], acc2, 0, 0, 0);
       }
-      // the last four k-steps only where this wave's bin range reaches them (the matrix
-      // instructions share the vector ALU's issue time: a k-step of zero weights is not free)
-      if (mel_long) {
+      // the last two groups of four k-steps only where this wave's bin range reaches them (the
+      // matrix instructions share the vector ALU's issue time: a k-step of zero weights is not free)
 #pragma unroll
-        for (int s = kMelSteps - 4; s < kMelSteps; s += 2) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], pa[s], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s + 1], pa[s + 1], acc2, 0, 0, 0);
+      for (int grp = kMelSteps / 4 - 2; grp < kMelSteps / 4; ++grp)
+        if (mel_groups > grp) {
+#pragma unroll
+          for (int s = 4 * grp; s < 4 * grp + 4; s += 2) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], pa[s], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s + 1], pa[s + 1], acc2, 0, 0, 0);
+          }
         }
-      }
       acc += acc2;
 #else
       acc[0] = Prow[0]; acc[1] = Prow[16]; acc[2] = bv[0]; acc[3] = bv[1];
@@ -774,7 +776,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         for (int r = 0; r < 4; ++r) mv[r] = mv[r] == 0.f ? kEps64 : mv[r];
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lm[r] = 4 * g4 + r < mel_nf ? fast_ln(mv[r]) : 0.f;
+      for (int r = 0; r < 4; ++r) lm[r] = g4 + 4 * r < mel_nf ? fast_ln(mv[r]) : 0.f;
       float* const tile_w = part + wave * kPartTile;
       if (g4 == 3) tile_w[((q >> 2) * kPartSlots + 16) * 4 + (q & 3)] = acc[3];
       if (OUT == kOutLogmel) {
@@ -782,14 +784,17 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         if (t < s_hi) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (4 * g4 + r < mel_nf) out_t0[(t - t0) * ld + mel_ff + 4 * g4 + r] = lm[r];
+            if (g4 + 4 * r < mel_nf) out_t0[(t - t0) * ld + mel_ff + g4 + 4 * r] = lm[r];
         }
       } else {
         // this wave's share of the DCT-II * lifter product (mfcc-self5.py:136-156): coefficient rows
-        // 4 g4 + r of frame q, summed over the wave's filters; the four shares meet in LDS
-        f32x4 pd = {0.f, 0.f, 0.f, 0.f};
+        // 4 g4 + r of frame q, summed over the wave's filters; the four shares meet in LDS.  k-step r
+        // takes the wave's filters 4 r .. 4 r + 3 (one per lane group), so a wave with few filters
+        // runs few steps
+        f32x4 pd = __builtin_amdgcn_mfma_f32_16x16x4f32(dw[0], lm[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pd = __builtin_amdgcn_mfma_f32_16x16x4f32(dw[r], lm[r], pd, 0, 0, 0);
+        for (int r = 1; r < 4; ++r)
+          if (4 * r < mel_nf) pd = __builtin_amdgcn_mfma_f32_16x16x4f32(dw[r], lm[r], pd, 0, 0, 0);
         *(f32x4*)__builtin_assume_aligned(tile_w + (g4 * kPartSlots + q) * 4, 16) = pd;
       }
     }

@@ -350,22 +350,32 @@ static int build_specialised(mfcc_plan* p) {
         es[0] = 0;
         for (int g = 1; g < 4; ++g) es[g] = std::max(es[g - 1], std::min(fb[g], mfcc::kNbin));
         es[4] = mfcc::kNbin;
+        // Cost of a wave in matrix instructions (they share the vector ALU's issue time, so every
+        // one counts): its filterbank k-steps, run in groups of four (16 bins), plus the k-steps
+        // of its share of the DCT product, one per four filters.
         int mx = 0, sum = 0, k0[4], st[4];
+        bool fits = true;
         for (int g = 0; g < 4; ++g) {
           // a wave's bin range starts at a multiple of 4 (its spectrum reads are 16-byte aligned)
-          const int lo = std::min(es[g], fb[g]) & ~3, hi = std::max(lb[g] + 1, es[g + 1]);
-          k0[g] = std::min(lo, hi);
+          // and early enough for all kMelSteps steps to stay inside the zero-padded row
+          int lo = std::min(es[g], fb[g]) & ~3;
+          const int hi = std::max(lb[g] + 1, es[g + 1]);
+          lo = std::min(std::min(lo, hi) & ~3, mfcc::kRowPad - 4 * mfcc::kMelSteps);
+          k0[g] = lo;
           st[g] = hi > lo ? (hi - lo + 3) / 4 : 0;
-          mx = std::max(mx, st[g]);
-          sum += st[g];
+          if (st[g] > mfcc::kMelSteps) fits = false;
+          const int cost = (st[g] + 3) / 4 * 4 + std::max(1, (cut[g + 1] - cut[g] + 3) / 4);
+          mx = std::max(mx, cost);
+          sum += cost;
         }
+        if (!fits) continue;
         if (mx < best_max || (mx == best_max && sum < best_sum)) {
           best_max = mx; best_sum = sum;
           for (int g = 0; g < 5; ++g) { best_cut[g] = cut[g]; best_es[g] = es[g]; }
           for (int g = 0; g < 4; ++g) { best_k0[g] = k0[g]; best_steps[g] = st[g]; }
         }
       }
-  if (best_max > mfcc::kMelSteps) return 1;  // this filterbank does not fit the specialised kernel's k-step budget
+  if (best_max == 1 << 30) return 1;  // no split fits the specialised kernel's k-step budget
   mfcc::PlanConst& pch = p->pc_host;
   memset(&pch, 0, sizeof(pch));
   mfcc::MelMap& pmap = pch.map;
@@ -380,7 +390,10 @@ static int build_specialised(mfcc_plan* p) {
     for (int sidx = 0; sidx < mfcc::kMelSteps; ++sidx)
       for (int lane = 0; lane < 64; ++lane) {
         // k-step sidx of lane group (lane >> 4) takes bin kstart + 16 (sidx / 4) + 4 (lane >> 4) + sidx % 4
-        const int k = pmap.kstart[g] + 16 * (sidx / 4) + 4 * (lane >> 4) + sidx % 4, j = lane & 15;
+        // row m = lane & 15 of the product lands in register m % 4 of lane group m / 4: give it the
+        // wave's filter m / 4 + 4 (m % 4), so that register r of the four lane groups holds filters
+        // 4 r .. 4 r + 3 and the chained DCT product needs only ceil(nfilt / 4) k-steps (row 15 maps to itself)
+        const int k = pmap.kstart[g] + 16 * (sidx / 4) + 4 * (lane >> 4) + sidx % 4, m = lane & 15, j = (m >> 2) + 4 * (m & 3);
         double w = 0.0;
         if (k < mfcc::kNbin) {
           if (j < pmap.nfilt[g]) w = bank[(size_t)(best_cut[g] + j) * mfcc::kNbin + k];
@@ -398,7 +411,7 @@ static int build_specialised(mfcc_plan* p) {
   for (int g = 0; g < 4; ++g)
     for (int lane = 0; lane < 64; ++lane)
       for (int r = 0; r < 4; ++r) {
-        const int c = lane & 15, j = 4 * (lane >> 4) + r;
+        const int c = lane & 15, j = (lane >> 4) + 4 * r;
         if (j < pmap.nfilt[g] && c < cfg->numcep)
           dctA[((size_t)g * 64 + lane) * 4 + r] = (float)dl[(size_t)(pmap.first_filter[g] + j) * cfg->numcep + c];
       }
