@@ -67,6 +67,24 @@ def config_b_variants(args):
                           "algorithmic_bytes": alg, "roofline_frac": round(alg / (t[1] * 1e-3) / 1e9 / HBM, 4)}), flush=True)
 
 
+def config_general(args):
+    """The general-geometry kernel on the headline shape (forced) and at 8 kHz with the derived 256-point FFT."""
+    n = 10000
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    audio = synth(n, gen).view(-1)
+    for name, kw, fs in (("general kernel forced, 400/160/512", dict(kernel="general"), 16000),
+                         ("general kernel, fs=8000 -> 200/80/256", dict(fs=8000), 8000),
+                         ("general kernel, pad_fac=3", dict(pad_fac=3), 16000)):
+        fe = mfcc_amd.MFCC("self5", **kw)
+        lay = fe.layout([UTT_LEN] * n)
+        out = torch.empty((lay.total_frames, 39), dtype=torch.float32, device="cuda")
+        t = timed(lambda: fe.forward(audio, lay, out=out), 5, 1)
+        alg = 2 * audio.numel() + 156 * lay.total_frames
+        print(json.dumps({"config": name, "general": fe.plan.general, "frames": lay.total_frames, "ms_min_med": [round(v, 4) for v in t],
+                          "frames_per_s": round(lay.total_frames / (t[1] * 1e-3), 1),
+                          "roofline_frac": round(alg / (t[1] * 1e-3) / 1e9 / HBM, 4)}), flush=True)
+
+
 def config_c(args):
     n = 10000
     gen = torch.Generator(device="cuda").manual_seed(1234)
@@ -83,12 +101,17 @@ def config_c(args):
         fe.forward(audio, lay, out=spec, kind="logspec")
         mfcc_amd.stack_context(spec, 17, frame_counts=[FPU] * n, out=ctx)
     t_both = timed(both, 5)
+    del spec
+    torch.cuda.empty_cache()
+    t_one = timed(lambda: mfcc_amd.spectrum_stack(fe, audio, lay, 17, out=ctx), 5)   # mfcc_forward_stacked: one launch
     alg = 2 * n * UTT_LEN + 4 * 257 * 17 * frames
     rec = {"config": "C: 257-bin log power spectrum + 17-frame stack, 10000 x 3 s", "frames": frames,
            "spec_ms_min_med": t_spec, "stack_ms_min_med": t_stack, "total_ms_min_med": t_both,
            "frames_per_s": round(frames / (t_both[1] * 1e-3), 1), "algorithmic_bytes": alg,
            "achieved_GBps": round(alg / (t_both[1] * 1e-3) / 1e9, 1),
            "roofline_frac": round(alg / (t_both[1] * 1e-3) / 1e9 / HBM, 4),
+           "one_launch_ms_min_med": t_one, "one_launch_frames_per_s": round(frames / (t_one[1] * 1e-3), 1),
+           "one_launch_roofline_frac": round(alg / (t_one[1] * 1e-3) / 1e9 / HBM, 4),
            "spec_only_bytes": 2 * n * UTT_LEN + 1028 * frames,
            "spec_only_frac": round((2 * n * UTT_LEN + 1028 * frames) / (t_spec[1] * 1e-3) / 1e9 / HBM, 4)}
     print(json.dumps(rec), flush=True)
@@ -196,12 +219,15 @@ def config_pcie(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="B,C,D,E,pcie")
+    ap.add_argument("--only", default="B,G,C,D,E,pcie")
     ap.add_argument("--utts-d", type=int, default=150000)
     args = ap.parse_args()
     which = set(args.only.split(","))
     if "B" in which:
         config_b_variants(args)
+        torch.cuda.empty_cache()
+    if "G" in which:
+        config_general(args)
         torch.cuda.empty_cache()
     if "C" in which:
         config_c(args)
