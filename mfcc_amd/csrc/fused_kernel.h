@@ -265,14 +265,20 @@ __device__ __forceinline__ StageCtx<T> stage_setup(const T* buf, int64_t total, 
 template <typename T, class G>
 __device__ __forceinline__ void stage_load(const StageCtx<T>& c, StageRegs& r, int batch_off, int tid) {
   // batch_off = (first frame of the batch - first frame of the tile) * step, in elements
-  constexpr int CE = 16 / (int)sizeof(T);  // elements per chunk
   constexpr int NR = sizeof(T) == 2 ? 2 : 3;
   r.delta = c.delta;
+  // Byte offsets from a wave-uniform base, kept non-negative so that each load is one instruction
+  // with a scalar base and a 32-bit vector offset (no 64-bit address arithmetic per lane).  The
+  // predecessor sample may lie up to 14 bytes in front of the tile's first chunk: its offsets are
+  // taken from 16 bytes below the base.
+  constexpr int SZ = (int)sizeof(T);
+  const char* const base_b = (const char*)c.base;
+  const int hi_b = c.hi_rel * SZ, front_b = c.front_rel * SZ + 16, last_b = c.last_rel * SZ + 16;
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
-    const int e = batch_off + (int)min((unsigned)(tid + 256 * k), c.nchunk - 1) * CE;
-    r.raw[k] = *(const uint4*)(c.base + min(e, c.hi_rel));
-    r.prev[k] = (float)c.base[min(max(e - 1, c.front_rel), c.last_rel)];
+    const int eb = batch_off * SZ + (int)min((unsigned)(tid + 256 * k), c.nchunk - 1) * 16;
+    r.raw[k] = *(const uint4*)(base_b + (unsigned)min(eb, hi_b));
+    r.prev[k] = (float)*(const T*)(base_b - 16 + (unsigned)min(max(eb + 16 - SZ, front_b), last_b));
   }
 }
 template <typename T, class G>
