@@ -151,6 +151,7 @@ struct PlanConst {
   int32_t floor_mel;
   float spec_scale;       // 1/(4*nfft) for power, 1/2 for magnitude (both exact powers of two)
   float log_floor;        // log-spectrum output: ln(max(v, log_floor)) when > 0 (anal_recog_nn_liste.m:529)
+  int32_t decim;          // 1: 512-point plan; 2: 256-point plan = the even bins of the 512-point transform
 };
 
 struct FusedParams {
@@ -601,6 +602,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
       float* const spec_row = (kSpecOut && !kStack && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
       const float spec_scale = kSpecOut ? pc->spec_scale : 0.f, spec_floor = kSpecOut ? pc->log_floor : 0.f;
+      const bool half_band = kSpecOut && pc->decim == 2;
       auto spec_value = [&](float p4) {
         // LDS rows would hold 4|X|^2 (power) or, after the square root, 2|X| (magnitude)
         float v = (mag ? __builtin_amdgcn_sqrtf(p4) : p4) * spec_scale;
@@ -635,8 +637,14 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
             // spectrum kinds: scale (sqrt, ln) and write the two bins of this lane straight from
             // registers to the output row of the frame; no trip through LDS, no barrier
             if (spec_row) {
-              spec_row[q + 16 * (h + s)] = spec_value(lo);
-              spec_row[256 - q - 16 * (h + s)] = spec_value(hi);
+              // a 256-point plan keeps the even bins (both bins of a lane have the parity of q)
+              if (!half_band) {
+                spec_row[q + 16 * (h + s)] = spec_value(lo);
+                spec_row[256 - q - 16 * (h + s)] = spec_value(hi);
+              } else if (!(q & 1)) {
+                spec_row[(q >> 1) + 8 * (h + s)] = spec_value(lo);
+                spec_row[128 - (q >> 1) - 8 * (h + s)] = spec_value(hi);
+              }
             }
           } else {
             P[q + 16 * (h + s)] = lo;
@@ -648,7 +656,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         if (kStack) {
           P[128] = spec_value(4.f * norm2(x[8]));
         } else if (kSpecOut) {
-          if (spec_row) spec_row[128] = spec_value(4.f * norm2(x[8]));
+          if (spec_row) spec_row[half_band ? 64 : 128] = spec_value(4.f * norm2(x[8]));
         } else {
           P[128] = 4.f * norm2(x[8]);
           P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-steps

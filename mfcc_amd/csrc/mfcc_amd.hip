@@ -320,7 +320,18 @@ static int build_specialised(mfcc_plan* p) {
   const int32_t nfft = p->nfft, size = p->frame_size;
   // ---- operands of the two matrix-core products (layout: see mfcc::MelMap) ----------------
   const int nmel = cfg->num_bins;
-  const std::vector<double> bank = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft, cfg->high_freq);
+  // The kernel always transforms 512 points.  A 256-point FFT of a frame of at most 256 samples
+  // (8 kHz: 200 samples, mfcc-self5.py:79-84) is every other bin of the 512-point FFT of the same
+  // zero-padded frame, X256[j] = X512[2 j]: the filterbank and the energy sum of such a plan carry
+  // their weights on the even bins of the 257-bin row and zeros on the odd ones.
+  const int decim = mfcc::kNfft / nfft;  // 1 or 2
+  std::vector<double> bank((size_t)nmel * mfcc::kNbin, 0.0);
+  {
+    const std::vector<double> own = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft, cfg->high_freq);
+    const int nb = nfft / 2 + 1;
+    for (int m = 0; m < nmel; ++m)
+      for (int k = 0; k < nb; ++k) bank[(size_t)m * mfcc::kNbin + (size_t)k * decim] = own[(size_t)m * nb + k];
+  }
   std::vector<int> first(nmel, mfcc::kNbin), last(nmel, -1);
   for (int m = 0; m < nmel; ++m)
     for (int k = 0; k < mfcc::kNbin; ++k)
@@ -397,7 +408,7 @@ static int build_specialised(mfcc_plan* p) {
         double w = 0.0;
         if (k < mfcc::kNbin) {
           if (j < pmap.nfilt[g]) w = bank[(size_t)(best_cut[g] + j) * mfcc::kNbin + k];
-          else if (j == mfcc::kMelCols && k >= best_es[g] && k < best_es[g + 1]) w = 1.0;
+          else if (j == mfcc::kMelCols && k >= best_es[g] && k < best_es[g + 1] && k % decim == 0) w = 1.0;
         }
         // four consecutive k-steps of a lane are 16 contiguous bytes: [wave][step/4][lane][step%4]
         melB[(((size_t)g * (mfcc::kMelSteps / 4) + sidx / 4) * 64 + lane) * 4 + sidx % 4] = (float)(w * (double)p->spec_scale);
@@ -438,6 +449,7 @@ static int build_specialised(mfcc_plan* p) {
   pch.floor_mel = cfg->floor_mel;
   pch.spec_scale = p->spec_scale;
   pch.log_floor = (float)cfg->log_floor;
+  pch.decim = decim;
   if ((rc = upload(std::vector<mfcc::PlanConst>(1, pch), &p->pc))) {
     return rc;
   }
@@ -570,7 +582,9 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
 
   const bool g16k = size == mfcc::Geom16k::kSize && step == mfcc::Geom16k::kStep;
   const bool g8k = size == mfcc::Geom8k::kSize && step == mfcc::Geom8k::kStep;
-  bool specialised = cfg->kernel == MFCC_KERNEL_AUTO && (g16k || g8k) && nfft == mfcc::kNfft && cfg->num_bins <= mfcc::kMaxMel &&
+  // 512-point FFT, or the 256-point FFT winfft derives for 200-sample frames (taken from the even bins)
+  const bool fft_ok = nfft == mfcc::kNfft || (g8k && nfft == mfcc::kNfft / 2);
+  bool specialised = cfg->kernel == MFCC_KERNEL_AUTO && (g16k || g8k) && fft_ok && cfg->num_bins <= mfcc::kMaxMel &&
                      cfg->numcep <= mfcc::kMaxCep && cfg->pad_fac == 2 && !cfg->keep_c0;
   int rc = MFCC_OK;
   try {
@@ -818,9 +832,10 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
   if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: null plan or layout");
   if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
   if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: the layout holds frame counts only (mfcc_layout_create_frames)");
-  if (plan->general)
-    return fail(MFCC_ERR_UNSUPPORTED, "mfcc_forward_stacked: this plan runs the general kernel (framing %d/%d, %d-point FFT); "
-                "use mfcc_forward + mfcc_stack_context", plan->frame_size, plan->frame_step, plan->nfft);
+  if (plan->general || plan->nfft != mfcc::kNfft)
+    return fail(MFCC_ERR_UNSUPPORTED, "mfcc_forward_stacked: built for 512-point plans of the specialised kernel (this one: framing %d/%d, "
+                "%d-point FFT%s); use mfcc_forward + mfcc_stack_context", plan->frame_size, plan->frame_step, plan->nfft,
+                plan->general ? ", general kernel" : "");
   {
     const int rc_l = layout_fits(plan, layout);
     if (rc_l) return rc_l;

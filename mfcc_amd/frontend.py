@@ -338,7 +338,7 @@ def spectrum_stack(fe, audio, layout, framenum, out=None, log=True):
     framenum = int(framenum)
     width = fe.plan.out_width("spec")
     shape = (layout.total_frames, framenum * width)
-    if framenum % 4 != 1 or framenum > 65 or fe.plan.general:
+    if framenum % 4 != 1 or framenum > 65 or fe.plan.general or fe.plan.num_fft != 512:
         spec = fe.forward(audio, layout, kind="logspec" if log else "spec")
         return stack_context(spec, framenum, frame_counts=np.diff(layout.frame_offsets), out=out)
     if out is None:

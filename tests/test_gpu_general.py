@@ -40,7 +40,9 @@ def test_other_frame_geometries_against_reference_goldens(M, golden, gname, vari
     fe = M.MFCC(variant, fs=fs, frame_time=frame_time, step_time=step_time)
     size, step, nfft = O.frame_geometry(fs, frame_time, step_time)
     assert (fe.plan.frame_size, fe.plan.frame_step, fe.plan.num_fft) == (size, step, nfft) and nfft == int(g[f"{gname}_nfft"])
-    assert fe.plan.general
+    # 8 kHz: 200/80-sample frames are a framing of the specialised kernel, whose 512-point transform
+    # holds the 256-point spectrum on its even bins; the other framings run the general kernel
+    assert fe.plan.general == (gname != "8k")
     packed = torch.from_numpy(np.concatenate(audios)).cuda()
     lay = fe.layout(lengths)
     out = fe.forward(packed, lay).cpu().numpy()
@@ -63,6 +65,13 @@ def test_other_frame_geometries_against_reference_goldens(M, golden, gname, vari
     # float32 samples take the same path
     outf = fe(packed.to(torch.float32), lengths=lengths).cpu().numpy()
     assert_cep(outf, out, f"{gname} float input", atol=2e-3 if variant == "self5" else 1e-3)
+    # and the general kernel agrees with whichever kernel ran (for 8 kHz: the specialised one)
+    gen = M.MFCC(variant, fs=fs, frame_time=frame_time, step_time=step_time, kernel="general")
+    assert gen.plan.general
+    assert_cep(gen.forward(packed, gen.layout(lengths)).cpu().numpy(), out, f"{gname} general vs selected kernel", atol=2e-3)
+    lspec = fe.forward(packed, lay, kind="logspec").cpu().numpy()
+    fin = spec > 1e-3 * spec.max(axis=1, keepdims=True)
+    assert np.abs(lspec[fin] - np.log(spec[fin])).max() < 1e-5
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -161,11 +170,12 @@ def test_reference_named_winfft_at_other_rates(M, golden, variant):
 
 
 def test_streaming_at_8khz_with_the_derived_256_point_fft(M):
-    """StreamingMFCC on a general plan: pushes + flush equal the offline rows."""
+    """StreamingMFCC at the framing winfft derives for 8 kHz (200/80 samples, 256-point FFT), on the
+    specialised and on the general kernel: pushes + flush equal the offline rows."""
     a = _synth(79, 12345)
-    for variant in VARIANTS:
-        s = M.StreamingMFCC(variant, n_streams=2, max_chunk=400, fs=8000)
-        assert s.plan.general and s.plan.num_fft == 256
+    for variant, kernel in [(v, k) for v in VARIANTS for k in ("auto", "general")]:
+        s = M.StreamingMFCC(variant, n_streams=2, max_chunk=400, fs=8000, kernel=kernel)
+        assert s.plan.general == (kernel == "general") and s.plan.num_fft == 256
         both = torch.from_numpy(np.stack([a, a[::-1].copy()])).cuda()
         got = _stream_all(s, both, [80, 333, 7]).cpu().numpy()
         assert_cep(got[0], O.mfcc39(a, variant, fs=8000, loop=False), f"8 kHz stream {variant}")
@@ -180,6 +190,10 @@ def test_layouts_and_plans_of_different_framings_do_not_mix(M):
         fe8.forward(a, fe16.layout([30000]))
     with pytest.raises(M.frontend.capi.MfccError):
         fe16.forward(a, fe8.layout([30000]))
+    # the one-launch stacked spectrum is built for 512-point plans; others take the two-kernel route inside spectrum_stack
+    lay8 = fe8.layout([30000])
+    two = M.stack_context(fe8.forward(a, lay8, kind="logspec"), 5, frame_counts=np.diff(lay8.frame_offsets))
+    assert two.shape[1] == 5 * 129 and torch.equal(M.spectrum_stack(fe8, a, lay8, 5), two)
     # same framing, other kernel: the general kernel's short tiles suit the specialised kernel
     gen = M.MFCC("self5", kernel="general")
     assert_cep(fe16.forward(a, gen.layout([30000])).cpu().numpy(), fe16(a).cpu().numpy(), "general-cut layout", atol=0)

@@ -631,7 +631,7 @@ def test_8khz_geometry_with_512_point_fft(variant):
     got = _stream_all(s, torch.from_numpy(audios[-1][None, :]).cuda(), [80, 333]).cpu().numpy()[0]
     assert_cep(got, O.mfcc39(audios[-1], variant, fs=8000, num_fft=512), "8 kHz stream")
     # the reference's own winfft takes a 256-point FFT at this frame size (mfcc-self5.py:79-84):
-    # that configuration runs the general kernel (tests/test_gpu_general.py)
+    # that configuration is checked against the reference's goldens in tests/test_gpu_general.py
     assert mfcc_amd.MFCC(variant, fs=8000).plan.num_fft == 256
 
 

@@ -73,7 +73,8 @@ def config_general(args):
     gen = torch.Generator(device="cuda").manual_seed(1234)
     audio = synth(n, gen).view(-1)
     for name, kw, fs in (("general kernel forced, 400/160/512", dict(kernel="general"), 16000),
-                         ("general kernel, fs=8000 -> 200/80/256", dict(fs=8000), 8000),
+                         ("fs=8000 -> 200/80 samples, 256-point FFT (specialised kernel, even bins of its 512-point transform), 6 s utterances", dict(fs=8000), 8000),
+                         ("general kernel forced, fs=8000 -> 200/80/256", dict(fs=8000, kernel="general"), 8000),
                          ("general kernel, pad_fac=3", dict(pad_fac=3), 16000)):
         fe = mfcc_amd.MFCC("self5", **kw)
         lay = fe.layout([UTT_LEN] * n)
