@@ -233,10 +233,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the compact config C / E figures")
     args = ap.parse_args()
+    # Defaults of config B: the part ramps its clocks up over the first ~35 launches of a cold start
+    # (per-launch times in profiles/r2_final_kernel_trace_durations.txt), so 60 untimed launches come first.
     if args.steps is None:
-        args.steps = 50 if args.config == "B" else 3
+        args.steps = 200 if args.config == "B" else 3
     if args.warmup is None:
-        args.warmup = 5 if args.config == "B" else 1
+        args.warmup = 60 if args.config == "B" else 1
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started by hand without a launcher: start one process per GPU and relay the result
