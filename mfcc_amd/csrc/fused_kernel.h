@@ -10,18 +10,24 @@
 //               1. all threads stage 15*160+400 samples (aligned 16-byte loads, converted to
 //                  float, pre-emphasised) into LDS -- each sample is read from HBM once per
 //                  batch although it belongs to 2.5 frames; batch b+1 is staged while the
-//                  matrix cores work on batch b;
+//                  filterbank of batch b runs;
 //               2. each wave transforms 4 frames, 16 lanes per frame (fft_lane.h), and leaves
 //                  the 257 spectrum values of each frame in LDS;                [barrier]
-//               3. the [16 x 257] x [257 x (nmel+1)] filterbank product runs on the matrix
-//                  cores (v_mfma_f32_16x16x4_f32, an exact f32 fma chain): every wave owns a
-//                  group of filter columns, so it takes ln of its sums at once;    [barrier]
-//               4. one wave (rotating) runs the [16 x nmel] x [nmel x numcep] DCT*lifter
-//                  product on the matrix cores, sets c0 := ln E and writes the static
-//                  features straight to their final place in the output rows.
-//   epilogue  the tile's static columns are read back (L2-hot) into LDS, delta and
-//             delta-delta are formed (4 halo frames were computed on each side where the
-//             utterance continues) and the remaining 2*numcep columns are written.
+//               3. the [filters x 257] x [257 x 16 frames] filterbank product runs as matrix
+//                  instructions (v_mfma_f32_16x16x4_f32, an exact f32 fma chain): every wave owns
+//                  a group of filters, takes ln of its sums at once and feeds them, still in
+//                  registers, to its share of the [numcep x filters] DCT*lifter product; the
+//                  four shares go to a small LDS tile;                            [barrier]
+//               4. the shares are summed, c0 := ln E, and the static row enters a ring of 32
+//                  rows in LDS.
+//   rows out  one batch later, when the rows t-4 .. t+4 of a frame exist, delta and delta-delta
+//             are formed from the ring and the whole row c | delta | delta-delta is stored: every
+//             output line is written once, nothing is read back (4 halo frames are computed on
+//             each side of a tile where the utterance continues).
+//
+// On gfx950 the fp32 matrix instruction runs on the vector ALU's pipe (a wave mix of both takes
+// the sum of their times), so every k-step counts like ~7 vector instructions: the plan splits
+// the filters so that the waves need few k-steps and the kernel skips those a wave does not need.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -35,8 +35,8 @@ constexpr int kGenMaxTile = 128;   // output frames per tile at most
 // Constant tables of a general plan (device memory).
 struct GeneralConst {
   const float* tw;        // [nfft/2][2]  exp(-2 pi i k / nfft)
-  const float* bank;      // [nmel][nbin] triangular weights (mfcc-self5.py:102-117)
-  const int32_t* band;    // [nmel][2]    first bin with a non-zero weight, one past the last
+  const float* bankc;     // triangular weights (mfcc-self5.py:102-117), compact: only the bins of each filter's band
+  const int32_t* band;    // [nmel][3]    first bin with a non-zero weight, one past the last, offset of the band in bankc
   const float* dctl;      // [nmel][numcep] DCT-II 'ortho' * lifter (mfcc-self5.py:136-156)
   const float* window;    // [frame_size] or nullptr
   int32_t frame_size, frame_step, nfft, log2m;  // log2m = log2(nfft / 2)
@@ -49,16 +49,20 @@ struct GeneralConst {
   float log_floor;
   float delta_denom;      // 2 * sum i^2, mfcc-self5.py:172
   int32_t stat_rows;      // rows of the statics / delta arrays in LDS (>= tile frames + 4 * pad_fac)
+  int32_t bankc_lds;      // > 0: floats of LDS that hold a copy of bankc (read from there)
+  int32_t dct_lds;        // > 0: floats of LDS that hold a copy of dctl
 };
 
-// dynamic LDS of the kernel, in floats: per wave a complex FFT buffer, a spectrum row and a
-// ln-mel row; per workgroup the static and delta rows of a tile (MFCC-39 only)
+// dynamic LDS of the kernel, in floats: the twiddle table (nfft floats), the filter weights and
+// the DCT matrix when the plan found room for them (bankc_lds, dct_lds floats; not counted by
+// general_smem_bytes), per wave a complex FFT buffer, a spectrum row and a ln-mel row; per
+// workgroup the static and delta rows of a tile (MFCC-39 only)
 __host__ __device__ inline int general_row_floats(int nfft) { return (nfft / 2 + 1 + 3) & ~3; }
 __host__ __device__ inline int general_wave_floats(int nfft, int nmel) {
   return nfft + general_row_floats(nfft) + ((nmel + 1 + 3) & ~3);
 }
 inline size_t general_smem_bytes(int nfft, int nmel, int numcep, int stat_rows) {
-  return ((size_t)4 * general_wave_floats(nfft, nmel) + (size_t)2 * stat_rows * numcep) * sizeof(float);
+  return ((size_t)nfft + (size_t)4 * general_wave_floats(nfft, nmel) + (size_t)2 * stat_rows * numcep) * sizeof(float);
 }
 
 __device__ __forceinline__ unsigned bit_reverse(unsigned v, int bits) { return bits ? __brev(v) >> (32 - bits) : 0u; }
@@ -82,11 +86,15 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = gc.nfft >> 1, nbin = M + 1;
   const int nmel = gc.nmel, ncep = gc.numcep, pf = gc.pad_fac;
-  float* const wbase = gsm + wave * general_wave_floats(gc.nfft, nmel);
+  const cf* const twl = (const cf*)gsm;                   // [M] exp(-2 pi i k / nfft): read by every butterfly, so kept in LDS
+  float* const tables = gsm + gc.nfft;                    // [bankc_lds] filter weights, [dct_lds] DCT * lifter
+  const float* const bankw = gc.bankc_lds ? tables : gc.bankc;
+  const float* const dctw = gc.dct_lds ? tables + gc.bankc_lds : gc.dctl;
+  float* const wbase = tables + gc.bankc_lds + gc.dct_lds + wave * general_wave_floats(gc.nfft, nmel);
   cf* const z = (cf*)wbase;                               // [M] complex
   float* const srow = wbase + gc.nfft;                    // [nbin] spectrum row
   float* const lrow = srow + general_row_floats(gc.nfft); // [nmel] ln mel, then ln E
-  float* const stat = gsm + 4 * general_wave_floats(gc.nfft, nmel);  // [stat_rows][ncep]
+  float* const stat = tables + gc.bankc_lds + gc.dct_lds + 4 * general_wave_floats(gc.nfft, nmel);  // [stat_rows][ncep]
   float* const dlt = stat + gc.stat_rows * ncep;                     // [stat_rows][ncep]
 
   const Tile tile = p.tiles[blockIdx.x];
@@ -101,6 +109,20 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
   const T* const x = (const T*)p.audio + s_off;
   const int64_t ld = p.out_ld;
   const bool mag = gc.spectrum != 0;
+
+  for (int i = tid; i < 2 * M; i += 256) gsm[i] = gc.tw[i];
+  for (int i = tid; i < gc.bankc_lds; i += 256) tables[i] = gc.bankc[i];  // the plan pads bankc to this length
+  for (int i = tid; i < gc.dct_lds; i += 256) tables[gc.bankc_lds + i] = i < nmel * ncep ? gc.dctl[i] : 0.f;
+  __syncthreads();
+  // band of this lane's filter(s): lane j and, beyond 64 filters, j + 64
+  int blo[2] = {0, 0}, bhi[2] = {0, 0}, boff[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (lane + 64 * u < nmel) {
+      blo[u] = gc.band[3 * (lane + 64 * u)];
+      bhi[u] = gc.band[3 * (lane + 64 * u) + 1];
+      boff[u] = gc.band[3 * (lane + 64 * u) + 2];
+    }
 
   for (int t = s_lo + wave; t < s_hi; t += 4) {
     // ---- framing (mfcc-self5.py:85-95): samples t*step .. +frame_size, zeros past the utterance end
@@ -128,7 +150,7 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
         const int pos = j & (half - 1);
         const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
         const int k = pos << (gc.log2m - s);  // W_M^(pos M / (2 half)) = W_nfft^(pos M / half)
-        const cf w = mk(gc.tw[2 * k], gc.tw[2 * k + 1]);
+        const cf w = twl[k];
         const cf a = z[i0], b = z[i1];
         const cf bw = mk(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
         z[i0] = a + bw;
@@ -148,7 +170,7 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
       } else {
         const cf a = z[k], b = z[M - k];
         const cf A = mk(a.x + b.x, a.y - b.y), B = mk(a.x - b.x, a.y + b.y);
-        const cf w = mk(gc.tw[2 * k], gc.tw[2 * k + 1]);
+        const cf w = twl[k];
         const cf C = mk(B.x * w.x - B.y * w.y, B.x * w.y + B.y * w.x);
         const float ur = A.x + C.y, ui = A.y - C.x;  // A - i C
         p4 = ur * ur + ui * ui;
@@ -166,11 +188,22 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
     for (int m = 32; m >= 1; m >>= 1) e += __shfl_xor(e, m, 64);
     if (e == 0.f) e = kEps64;
     const float lne = logf(e);
-    for (int j = lane; j < nmel; j += 64) {
-      const int lo = gc.band[2 * j], hi = gc.band[2 * j + 1];
-      const float* const w = gc.bank + (size_t)j * nbin;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = lane + 64 * u;
+      if (j >= nmel) break;
+      const int lo = blo[u], hi = bhi[u];
+      const float* const w = bankw + boff[u] - lo;  // w[k] = weight of bin k, lo <= k < hi
       float acc = 0.f;
-      for (int k = lo; k < hi; ++k) acc = fmaf(srow[k], w[k], acc);
+      int k = lo;
+      for (; k + 4 <= hi; k += 4) {  // four weights in flight; the sum keeps the order of the bins
+        const float w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
+        acc = fmaf(srow[k], w0, acc);
+        acc = fmaf(srow[k + 1], w1, acc);
+        acc = fmaf(srow[k + 2], w2, acc);
+        acc = fmaf(srow[k + 3], w3, acc);
+      }
+      for (; k < hi; ++k) acc = fmaf(srow[k], w[k], acc);
       if (gc.floor_mel && acc == 0.f) acc = kEps64;
       lrow[j] = logf(acc);
     }
@@ -188,7 +221,15 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
     // ---- DCT-II * lifter, c0 := ln E (mfcc-self5.py:136-167)
     for (int c = lane; c < ncep; c += 64) {
       float acc = 0.f;
-      for (int n = 0; n < nmel; ++n) acc = fmaf(lrow[n], gc.dctl[n * ncep + c], acc);
+      int n = 0;
+      for (; n + 4 <= nmel; n += 4) {
+        const float w0 = dctw[n * ncep + c], w1 = dctw[(n + 1) * ncep + c], w2 = dctw[(n + 2) * ncep + c], w3 = dctw[(n + 3) * ncep + c];
+        acc = fmaf(lrow[n], w0, acc);
+        acc = fmaf(lrow[n + 1], w1, acc);
+        acc = fmaf(lrow[n + 2], w2, acc);
+        acc = fmaf(lrow[n + 3], w3, acc);
+      }
+      for (; n < nmel; ++n) acc = fmaf(lrow[n], dctw[n * ncep + c], acc);
       if (c == 0 && !gc.keep_c0) acc = lne;
       if (full) stat[(t - s_lo) * ncep + c] = acc;
       else if (own) p.out[(f_off + t) * ld + c] = acc;

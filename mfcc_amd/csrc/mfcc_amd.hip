@@ -460,30 +460,40 @@ static int build_specialised(mfcc_plan* p) {
 static int build_general(mfcc_plan* p) {
   const mfcc_config* const cfg = &p->cfg;
   const int nfft = p->nfft, nbin = nfft / 2 + 1, nmel = cfg->num_bins, ncep = cfg->numcep, pf = cfg->pad_fac;
-  // LDS budget: 64 KiB per workgroup; what the four waves' FFT buffers leave goes to the tile's
-  // static and delta rows
-  const size_t wave_bytes = (size_t)4 * mfcc::general_wave_floats(nfft, nmel) * sizeof(float);
+  // filter weights, compact: filter m's weights of the bins band[3m] .. band[3m+1]-1 start at band[3m+2]
+  const std::vector<double> bank = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft, cfg->high_freq);
+  std::vector<float> bankc;
+  std::vector<int32_t> band((size_t)3 * nmel, 0);
+  for (int m = 0; m < nmel; ++m) {
+    int lo = nbin, hi = 0;
+    for (int k = 0; k < nbin; ++k)
+      if (bank[(size_t)m * nbin + k] != 0.0) { lo = std::min(lo, k); hi = std::max(hi, k + 1); }
+    lo = std::min(lo, hi);
+    band[3 * m] = lo;
+    band[3 * m + 1] = hi;
+    band[3 * m + 2] = (int32_t)bankc.size();
+    for (int k = lo; k < hi; ++k) bankc.push_back((float)bank[(size_t)m * nbin + k]);
+  }
+  if (bankc.empty()) bankc.push_back(0.f);
+  // LDS budget: 64 KiB per workgroup.  The twiddles and the four waves' buffers always live there;
+  // the filter weights and the DCT matrix join them when the tile's static and delta rows still
+  // get a useful share of the rest (they are read from global memory otherwise).
+  const size_t fixed_bytes = ((size_t)nfft + (size_t)4 * mfcc::general_wave_floats(nfft, nmel)) * sizeof(float);
   const size_t row_bytes = (size_t)2 * ncep * sizeof(float);
-  const int64_t rows_fit = ((int64_t)65536 - (int64_t)wave_bytes) / (int64_t)row_bytes;
+  const size_t want_rows = (size_t)4 * pf + 32;
+  size_t table_floats = 0;
+  int bank_lds = 0, dct_lds = 0;
+  const size_t bank_pad = (bankc.size() + 3) & ~(size_t)3, dct_pad = ((size_t)nmel * ncep + 3) & ~(size_t)3;
+  bankc.resize(bank_pad, 0.f);  // the kernel copies whole 16-byte pieces
+  if (fixed_bytes + (table_floats + bank_pad) * sizeof(float) + want_rows * row_bytes <= 65536) { bank_lds = 1; table_floats += bank_pad; }
+  if (fixed_bytes + (table_floats + dct_pad) * sizeof(float) + want_rows * row_bytes <= 65536) { dct_lds = 1; table_floats += dct_pad; }
+  const int64_t rows_fit = ((int64_t)65536 - (int64_t)fixed_bytes - (int64_t)(table_floats * sizeof(float))) / (int64_t)row_bytes;
   const int rows = (int)std::min<int64_t>(rows_fit, mfcc::kGenMaxTile + 4 * pf);
   if (rows - 4 * pf < 4)
     return fail(MFCC_ERR_UNSUPPORTED, "num_fft=%d, num_bins=%d, numcep=%d, pad_fac=%d need more LDS than a workgroup has", nfft, nmel, ncep, pf);
   p->gen_nt_max = rows - 4 * pf;
-  p->gen_smem = mfcc::general_smem_bytes(nfft, nmel, ncep, rows);
+  p->gen_smem = mfcc::general_smem_bytes(nfft, nmel, ncep, rows) + table_floats * sizeof(float);
 
-  const std::vector<double> bank = mfcc::melbank(cfg->fs, nmel, cfg->low_freq, nfft, cfg->high_freq);
-  std::vector<float> bankf(bank.size());
-  std::vector<int32_t> band((size_t)2 * nmel, 0);
-  for (int m = 0; m < nmel; ++m) {
-    int lo = nbin, hi = 0;
-    for (int k = 0; k < nbin; ++k) {
-      const double w = bank[(size_t)m * nbin + k];
-      bankf[(size_t)m * nbin + k] = (float)w;
-      if (w != 0.0) { lo = std::min(lo, k); hi = std::max(hi, k + 1); }
-    }
-    band[2 * m] = std::min(lo, hi);
-    band[2 * m + 1] = hi;
-  }
   const std::vector<double> dl = mfcc::dct_lifter(nmel, ncep, cfg->lift_factor, true);
   std::vector<float> dlf(dl.begin(), dl.end());
   std::vector<float> win;
@@ -492,13 +502,15 @@ static int build_general(mfcc_plan* p) {
     win.assign(h.begin(), h.end());
   }
   int rc;
-  if ((rc = upload(mfcc::twiddle_half(nfft), &p->g_tw)) || (rc = upload(bankf, &p->g_bank)) || (rc = upload(band, &p->g_band)) ||
+  if ((rc = upload(mfcc::twiddle_half(nfft), &p->g_tw)) || (rc = upload(bankc, &p->g_bank)) || (rc = upload(band, &p->g_band)) ||
       (rc = upload(dlf, &p->g_dctl)) || (rc = upload(win, &p->g_window)))
     return rc;
   mfcc::GeneralConst& g = p->gc_host;
   memset(&g, 0, sizeof(g));
   g.tw = p->g_tw;
-  g.bank = p->g_bank;
+  g.bankc = p->g_bank;
+  g.bankc_lds = bank_lds ? (int32_t)bank_pad : 0;
+  g.dct_lds = dct_lds ? (int32_t)dct_pad : 0;
   g.band = p->g_band;
   g.dctl = p->g_dctl;
   g.window = p->g_window;
