@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <numeric>
 #include <vector>
 
 #include "fused_kernel.h"
@@ -111,13 +112,34 @@ int cmvn_static_scratch(double** out) {
   return MFCC_OK;
 }
 
+// Workgroups of 256 threads for the flat (16-byte piece) forms of the CMVN kernels: a multiple of
+// `unit` = the smallest count for which four times the thread count is a multiple of ncol, about
+// `want` of them, at most `cap`.  0 = the flat form does not apply (rows not back to back, base
+// not 16-byte aligned, or no such count within the cap).
+int cmvn_flat_blocks(const float* feats, int64_t feats_ld, int32_t ncol, int64_t want, int64_t cap) {
+  if (feats_ld != ncol || ((uintptr_t)feats & 15)) return 0;
+  const int64_t m = ncol / std::gcd((int64_t)ncol, (int64_t)4);
+  const int64_t unit = m / std::gcd(m, (int64_t)256);
+  if (unit > cap) return 0;
+  const int64_t n = std::max<int64_t>(1, std::min(want, cap) / unit) * unit;
+  return (int)n;
+}
+
 // Both stages of the CMVN reduction on `st`, partial sums in `partial` (>= nblk*2*ncol doubles).
 int launch_cmvn(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums, double* partial, int nblk,
                 int64_t rows_per_block, hipStream_t st) {
-  int threads = 256;
-  while (threads < ncol) threads += 64;
-  hipLaunchKernelGGL(mfcc::cmvn_partial_kernel, dim3((unsigned)nblk), dim3(threads), 2 * threads * sizeof(double), st, feats, feats_ld,
-                     n_rows, ncol, rows_per_block, partial);
+  // rows back to back: 16-byte pieces, about 16 per thread, kCmvnMaxBlocks workgroups at most
+  const int64_t n_elems = n_rows * ncol;
+  const int flat = cmvn_flat_blocks(feats, feats_ld, ncol, (n_elems / 4 + 256 * 16 - 1) / (256 * 16), mfcc::kCmvnMaxBlocks);
+  if (flat) {
+    nblk = flat;
+    hipLaunchKernelGGL(mfcc::cmvn_partial_flat_kernel, dim3((unsigned)nblk), dim3(256), 0, st, feats, n_elems, ncol, partial);
+  } else {
+    int threads = 256;
+    while (threads < ncol) threads += 64;
+    hipLaunchKernelGGL(mfcc::cmvn_partial_kernel, dim3((unsigned)nblk), dim3(threads), 2 * threads * sizeof(double), st, feats, feats_ld,
+                       n_rows, ncol, rows_per_block, partial);
+  }
   hipLaunchKernelGGL(mfcc::cmvn_finish_kernel, dim3(2 * (unsigned)ncol), dim3(256), 0, st, partial, nblk, ncol, n_rows, sums);
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
@@ -1048,6 +1070,16 @@ int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol
   if (n_rows == 0) return MFCC_OK;
   if (!feats || !mm || !vv) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_apply: null pointer");
   if (ncol > 4096) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_cmvn_apply: more than 4096 columns");
+  {
+    // rows back to back: 16-byte pieces, about 8 per thread
+    const int64_t n_elems = n_rows * ncol;
+    const int flat = cmvn_flat_blocks(feats, feats_ld, ncol, (n_elems / 4 + 256 * 8 - 1) / (256 * 8), 16384);
+    if (flat) {
+      hipLaunchKernelGGL(mfcc::cmvn_apply_flat_kernel, dim3((unsigned)flat), dim3(256), 0, (hipStream_t)stream, feats, n_elems, ncol, mm, vv);
+      HIP_TRY(hipGetLastError());
+      return MFCC_OK;
+    }
+  }
   const int rows_per_block = std::max(1, 16384 / ncol);
   const int64_t nblk = (n_rows + rows_per_block - 1) / rows_per_block;
   if (nblk > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_cmvn_apply: too many rows per call");

@@ -371,6 +371,63 @@ __global__ void cmvn_partial_kernel(const float* __restrict__ x, int64_t ld, int
   }
 }
 
+// Stage 1 for rows that lie back to back (ld == ncol, 16-byte aligned base): the array is one
+// stream of 16-byte pieces, thread g of the G = 256 * gridDim.x threads takes the pieces g, g + G,
+// g + 2G, ...  The host picks G so that 4 G is a multiple of ncol: the four elements of every piece
+// of a thread then belong to the same four columns ((4 g + k) mod ncol), and the thread keeps one
+// float64 sum and sum of squares for each.  Loads are whole 16-byte pieces, coalesced, several in
+// flight.  The workgroup's 1024 sums meet in LDS, where element e belongs to column
+// (1024 blockIdx.x + e) mod ncol; column c is added up in ascending e.  Same fixed order on every
+// launch, no atomics.
+__global__ void __launch_bounds__(256) cmvn_partial_flat_kernel(const float* __restrict__ x, int64_t n_elems, int ncol,
+                                                                double* __restrict__ partial) {
+  __shared__ double red[2][1024];
+  const int64_t G = (int64_t)gridDim.x * 256, g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n4 = n_elems >> 2;
+  const float4* const x4 = (const float4*)__builtin_assume_aligned(x, 16);
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+  auto add = [&](const float4 v) {
+    const double a = v.x, b = v.y, c = v.z, d = v.w;
+    s[0] += a; ss[0] = fma(a, a, ss[0]);
+    s[1] += b; ss[1] = fma(b, b, ss[1]);
+    s[2] += c; ss[2] = fma(c, c, ss[2]);
+    s[3] += d; ss[3] = fma(d, d, ss[3]);
+  };
+  int64_t i = g;
+  for (; i + 7 * G < n4; i += 8 * G) {  // eight pieces in flight
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x4[i + u * G];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) add(v[u]);
+  }
+  for (; i < n4; i += G) add(x4[i]);
+  if (i == n4) {  // the last, incomplete piece (n_elems % 4 elements) falls to the thread next in turn
+    for (int k = 0; k < (int)(n_elems & 3); ++k) {
+      const double a = x[4 * n4 + k];
+      s[k] += a;
+      ss[k] = fma(a, a, ss[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[0][4 * threadIdx.x + k] = s[k];
+    red[1][4 * threadIdx.x + k] = ss[k];
+  }
+  __syncthreads();
+  const int off = (int)(((int64_t)blockIdx.x * 1024) % ncol);
+  for (int c = threadIdx.x; c < ncol; c += 256) {
+    double a = 0.0, b = 0.0;
+    for (int e = c >= off ? c - off : c - off + ncol; e < 1024; e += ncol) {
+      a += red[0][e];
+      b += red[1][e];
+    }
+    double* const p = partial + (int64_t)blockIdx.x * 2 * ncol;
+    p[c] = a;
+    p[ncol + c] = b;
+  }
+}
+
 __global__ void __launch_bounds__(256) cmvn_finish_kernel(const double* __restrict__ partial, int nblk, int ncol,
                                                           int64_t n_rows, double* __restrict__ sums) {
   __shared__ double red[256];
@@ -414,6 +471,33 @@ __global__ void __launch_bounds__(256) cmvn_apply_kernel(float* __restrict__ x, 
     c += dc;
     if (c >= ncol) { c -= ncol; ++r; }
   }
+}
+
+// The same update for rows that lie back to back (ld == ncol, 16-byte aligned base), as a stream
+// of 16-byte pieces: with 4 * (number of threads) a multiple of ncol every piece of a thread has
+// the same four columns, so their constants stay in registers and a piece is one load, four
+// multiply-adds' worth of work and one store.
+__global__ void __launch_bounds__(256) cmvn_apply_flat_kernel(float* __restrict__ x, int64_t n_elems, int ncol,
+                                                              const float* __restrict__ mm, const float* __restrict__ vv) {
+  const int64_t G = (int64_t)gridDim.x * 256, g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n4 = n_elems >> 2;
+  float m[4], v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = (int)((4 * g + k) % ncol);
+    m[k] = mm[c];
+    v[k] = vv[c];
+  }
+  float4* const x4 = (float4*)__builtin_assume_aligned(x, 16);
+  auto upd = [&](float4 a) { return make_float4((a.x + m[0]) * v[0], (a.y + m[1]) * v[1], (a.z + m[2]) * v[2], (a.w + m[3]) * v[3]); };
+  int64_t i = g;
+  for (; i + 3 * G < n4; i += 4 * G) {
+    const float4 a0 = x4[i], a1 = x4[i + G], a2 = x4[i + 2 * G], a3 = x4[i + 3 * G];
+    x4[i] = upd(a0); x4[i + G] = upd(a1); x4[i + 2 * G] = upd(a2); x4[i + 3 * G] = upd(a3);
+  }
+  for (; i < n4; i += G) x4[i] = upd(x4[i]);
+  if (i == n4)
+    for (int k = 0; k < (int)(n_elems & 3); ++k) x[4 * n4 + k] = (x[4 * n4 + k] + m[k]) * v[k];
 }
 
 // Per-utterance scalar normalisation (x - mean) / std with mean and population std taken over

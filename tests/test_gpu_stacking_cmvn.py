@@ -114,6 +114,35 @@ def test_cmvn_sums_are_bit_reproducible_and_match_float64(M):
     assert np.allclose(c.cpu().numpy(), got, rtol=1e-13)
 
 
+def test_cmvn_contiguous_and_strided_rows_agree(M):
+    """Rows back to back take the 16-byte-piece kernels, a column slice of a wider array (or a base
+    that is not 16-byte aligned) the row-wise ones: same sums to float64 rounding, same normalised
+    values to the bit; element counts that are not multiples of four, widths that share factors
+    with four."""
+    rng = np.random.default_rng(33)
+    for n, d in ((70001, 39), (5003, 257), (999, 40), (4097, 6), (3, 39), (2, 1), (100003, 13)):
+        x = (rng.standard_normal((n, d)) * 4 - 2).astype(np.float32)
+        wide = torch.zeros((n, d + 3), dtype=torch.float32, device="cuda")
+        wide[:, :d] = torch.from_numpy(x).cuda()
+        flat = wide[:, :d].contiguous()
+        shifted = torch.empty(n * d + 1, dtype=torch.float32, device="cuda")[1:].view(n, d)   # base 4 bytes off a 16-byte boundary
+        shifted.copy_(flat)
+        cnt, s, ss = O.cmvn_sums(x)
+        for t in (flat, wide[:, :d], shifted):
+            got = M.cmvn_accumulate(t).cpu().numpy()
+            assert got[0] == cnt
+            assert np.allclose(got[1:1 + d], s, rtol=1e-12, atol=1e-6) and np.allclose(got[1 + d:], ss, rtol=1e-12)
+        sums = M.cmvn_accumulate(flat)
+        assert torch.equal(sums, M.cmvn_accumulate(flat, static=True))
+        mm, vv = M.cmvn_constants(sums)
+        a = M.cmvn_apply(flat.clone(), mm, vv)
+        b = M.cmvn_apply(wide.clone()[:, :d], mm, vv)
+        c = M.cmvn_apply(shifted, mm, vv)
+        assert torch.equal(a, b) and torch.equal(a, c)
+        ref = (x.astype(np.float32) + mm.cpu().numpy()) * vv.cpu().numpy()
+        assert np.array_equal(a.cpu().numpy(), ref.astype(np.float32))
+
+
 def test_cmvn_chain_on_mfcc_output(M):
     """forward -> accumulate -> constants -> apply on the product's own MFCC rows, checked against
     float64 numpy statistics of the oracle's features (a strided sample of the utterances)."""
