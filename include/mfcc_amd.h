@@ -152,9 +152,9 @@ int32_t mfcc_out_width(const mfcc_plan* plan, int32_t out_kind);
  * MLP_5hidlayer_40.py:244-248) straight from audio in one launch: winfft's spectrum rows
  * (mfcc-self5.py:96-99; their natural log for MFCC_OUT_LOGSPEC) stacked as padUtterance + slidingWin do
  * (MLP_5hidlayer_40.py:70-105): out[t, f*B + c] = spec[clamp(t + f - (N-1)/2, 0, F_u - 1), c], B = nfft/2+1.
- * Every spectrum row is computed once and written to the N output rows it belongs to.
+ * Every spectrum row is computed once, kept in LDS, and each output row leaves as one contiguous write.
  * out: [total_frames, framenum * B] contiguous floats, 16-byte aligned; out_kind MFCC_OUT_SPEC or
- * MFCC_OUT_LOGSPEC; framenum = 1, 5, 9, 13, 17 ... 65 (MFCC_ERR_UNSUPPORTED otherwise: use mfcc_forward +
+ * MFCC_OUT_LOGSPEC; framenum = 1, 5, 9, 13 or 17 (MFCC_ERR_UNSUPPORTED otherwise: use mfcc_forward +
  * mfcc_stack_context, which take any odd framenum and any feature width). */
 int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype,
                          int32_t framenum, float* out, int32_t out_kind, void* stream);

@@ -109,6 +109,16 @@ constexpr int kTwUnt = 0, kTwSt1 = 8;                // complex index of the fir
 constexpr int kTwFloats = 16 * kTwPitch;
 // ring_pitch = floats per ring row: numcep where it is a compile-time constant, else kMaxCep
 constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + kPartFloats + kRingRows * ring_pitch + kTwFloats; }
+// Stacked spectrum kinds: instead of the partial-DCT tiles and the statics ring, a ring of the last
+// 32 spectrum rows (frame s of the tile at ring row (s - s_lo) mod 32, 257 values behind a phase of
+// 0..3 floats), from which whole output rows are written.  81 632 bytes: two workgroups per CU
+// (the kernel is bound by its stores; the transforms of one workgroup hide under the stores of the other).
+constexpr int kSRingRows = 32;
+constexpr int kSRingPitch = 268;
+constexpr int kStackMaxN = 17;                        // context windows up to 17 frames: 2 * (N / 2) + 16 <= kSRingRows
+constexpr int smem_floats_stacked() { return kXbufFloats + kAbufFloats + kSRingRows * kSRingPitch + kTwFloats; }
+static_assert(smem_floats_stacked() * 4 <= 64 * 1280, "stacked kinds no longer fit two workgroups per CU");
+static_assert(2 * (kStackMaxN / 2) + kBatch <= kSRingRows, "spectrum ring too short for the context window");
 // gfx950 hands out LDS in units of 1280 bytes; three workgroups per CU fit while each takes at
 // most 42 units of the CU's 128.  The 13-coefficient kernels meet that exactly.
 static_assert(smem_floats(13) * 4 <= 42 * 1280, "LDS carve no longer allows three workgroups per CU");
@@ -356,11 +366,12 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const xbuf = smem;
   float* const abuf = xbuf + kXbufFloats;
   constexpr int RP = NCEP > 0 ? NCEP : kMaxCep;  // floats per row of the statics ring
+  constexpr bool kStack = (OUT == kOutSpecStack || OUT == kOutLogspecStack);
   float* const part = abuf + kAbufFloats;
   float* const ring = part + kPartFloats;
-  float* const twl = ring + kRingRows * RP;
+  float* const sring = abuf + kAbufFloats;  // stacked kinds: ring of spectrum rows in place of part / ring
+  float* const twl = kStack ? sring + kSRingRows * kSRingPitch : ring + kRingRows * RP;
 
-  constexpr bool kStack = (OUT == kOutSpecStack || OUT == kOutLogspecStack);
   constexpr bool kSpecOut = (OUT == kOutSpec || OUT == kOutLogspec || kStack);
   constexpr bool kLogOut = (OUT == kOutLogspec || OUT == kOutLogspecStack);
   const int tid = threadIdx.x;
@@ -377,8 +388,12 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const int64_t f_off = p.frame_off[tile.utt];
   const int nframes = (int)(p.frame_off[tile.utt + 1] - f_off);
   const int t0 = tile.t0, nt = tile.nt;
-  const int s_lo = (OUT == kOutMfcc39) ? max(0, t0 - kHalo) : t0;
-  const int s_hi = (OUT == kOutMfcc39) ? min(nframes, t0 + nt + kHalo) : t0 + nt;
+  // frames this tile computes: its own, plus what the rows at its ends reach for where the utterance
+  // continues (4 frames for delta-delta, half a context window for the stacked kinds)
+  // (a stacked row also completes the 16-byte chunk it shares with the row before it: one frame back at least)
+  const int reach = (OUT == kOutMfcc39) ? kHalo : (kStack ? p.stack_n >> 1 : 0);
+  const int s_lo = (reach || kStack) ? max(0, t0 - max(reach, kStack ? 1 : 0)) : t0;
+  const int s_hi = (reach || kStack) ? min(nframes, t0 + nt + reach) : t0 + nt;
   const int nmel = pc->nmel;
   const int ncep = NCEP > 0 ? NCEP : pc->numcep;
   const int ld = (int)p.out_ld;
@@ -480,6 +495,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   MFCC_STAMP(tk0);
 #endif
+  int stack_next = t0;  // stacked kinds: first output row not yet written
   for (int tb = s_lo; tb < s_hi; tb += kBatch) {
     MFCC_STAMP(ta);
     __builtin_amdgcn_s_setprio(MFCC_PRIO_FFT);
@@ -600,11 +616,12 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           bv[s] = w4.x; bv[s + 1] = w4.y; bv[s + 2] = w4.z; bv[s + 3] = w4.w;
         }
       }
-      // Stacked kinds keep the finished spectrum rows in LDS, each shifted by the 16-byte phase
-      // (0..3 floats) its copies will have in the output, so that the scatter below moves aligned
-      // 16-byte chunks: element c of frame s lands at output float (f_off + t) N B + f B + c with
-      // s = t + f - h, which is congruent to f_off + s + h + c mod 4 for B = 257 and N % 4 == 1.
-      float* const P = xbuf + fb * 512 + row_skew(fb) + (kStack ? (int)((f_off + tb + fb + (p.stack_n >> 1)) & 3) : 0);
+      // Stacked kinds keep the finished spectrum rows in a ring in LDS, each shifted by the 16-byte
+      // phase (0..3 floats) its copies will have in the output, so that the row writer below moves
+      // aligned 16-byte chunks: element c of frame s lands at output float (f_off + t) N B + f B + c
+      // with s = t + f - h, which is congruent to f_off + s + h + c mod 4 for B = 257 and N % 4 == 1.
+      float* const P = kStack ? sring + ((tb + fb - s_lo) & (kSRingRows - 1)) * kSRingPitch + (int)((f_off + tb + fb + (p.stack_n >> 1)) & 3)
+                              : xbuf + fb * 512 + row_skew(fb);
       // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
       float* const spec_row = (kSpecOut && !kStack && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
       const float spec_scale = kSpecOut ? pc->spec_scale : 0.f, spec_floor = kSpecOut ? pc->log_floor : 0.f;
@@ -688,60 +705,90 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     const bool more = tb + kBatch < s_hi;
 
     if (kStack) {
-      // ---- context stacking (padUtterance + slidingWin, MLP_5hidlayer_40.py:70-105), write-driven:
-      // out[t, f B + c] = spec[clamp(t + f - h), c], so the row of frame s is the column block
-      // f = s - t + h of the output rows t = s - h .. s + h (inside the utterance), and the first /
-      // last frame also fills the blocks whose window index was clamped.  Every (frame, output row)
-      // pair is one 1028-byte copy LDS -> HBM done by one wave: 16-byte chunks (plain stores: L2
-      // merges the chunks and the edge floats of neighbouring blocks into whole lines; non-temporal
-      // stores measured 6 % slower here) plus up to three single floats at each end.
+      // ---- context stacking (padUtterance + slidingWin, MLP_5hidlayer_40.py:70-105):
+      // out[t, f B + c] = spec[clamp(t + f - h), c].  Row-driven: once the frames t - h .. t + h of an
+      // output row exist in the ring, one wave writes the whole row (N B contiguous floats) front to
+      // back with aligned 16-byte stores -- the order HBM takes best (a frame-by-frame scatter of
+      // 1028-byte pieces with single floats at their ends measured 25 % slower).  Per block f: the
+      // whole 16-byte chunks inside it come straight from the source row (aligned in LDS by its
+      // phase); the chunk that straddles two blocks (or two rows) is put together from single floats
+      // by one lane.  Only the first and last chunk of an utterance are partial.
       stage_ld(tb + kBatch);
       constexpr int B = kNbin;
       const int N = p.stack_n, hN = N >> 1;
       const int64_t W = (int64_t)N * B;
       float* const out_u = p.out + f_off * W;  // output row 0 of this utterance
-      const int nrow = min(kBatch, s_hi - tb);
+      const int done = min(tb + kBatch, s_hi);  // frames 0 .. done-1 of the utterance are (or were) in the ring
+      const int t_end = min(done == nframes ? nframes : done - hN, t0 + nt);
       typedef float f32x4_t __attribute__((ext_vector_type(4)));
-      // wave w scatters frame slots w, w + 4, w + 8, w + 12: the row is read from LDS once and
-      // stored to each of its output rows (consecutive t, block f falling: + (W - B) floats a step)
-      for (int i = wave; i < nrow; i += 4) {
-        const int sfrm = tb + i;
-        const int a = (int)((f_off + sfrm + hN) & 3);  // phase of the row: LDS and output alike
-        const float* const src = xbuf + i * 512 + row_skew(i) + a;
-        const int c0 = (4 - a) & 3, nbody = (B - c0) >> 2, ntail = B - c0 - 4 * nbody;
-        const bool body = lane < nbody, edge = lane < c0 + ntail;
-        const int ce = lane < c0 ? lane : 4 * nbody + lane;  // head floats 0 .. c0-1, tail floats after the chunks
-        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-        float ve = 0.f;
-        if (body) v = *(const f32x4_t*)__builtin_assume_aligned(src + c0 + 4 * lane, 16);
-        if (edge) ve = src[ce];
-        const int j_lo = max(0, hN - sfrm), j_hi = min(N - 1, nframes - 1 - sfrm + hN);  // t = sfrm - h + j inside [0, F)
-        float* d = out_u + (int64_t)(sfrm - hN + j_lo) * W + (int64_t)(N - 1 - j_lo) * B;
-        for (int j = j_lo; j <= j_hi; ++j, d += W - B) {
-          if (body) *(f32x4_t*)__builtin_assume_aligned(d + c0 + 4 * lane, 16) = v;
-          if (edge) d[ce] = ve;
+      auto ring_row = [&](int sfrm) { return sring + ((sfrm - s_lo) & (kSRingRows - 1)) * kSRingPitch + (int)((f_off + sfrm + hN) & 3); };
+      for (int t = stack_next + wave; t < t_end; t += 4) {
+        const int a = (int)((f_off + t) & 3);  // floats of the row's start past a 16-byte boundary (W % 4 == 1)
+        float* const orow = out_u + (int64_t)t * W;
+        const bool interior = t >= hN && t + hN <= nframes - 1;  // no window index of this row is clamped
+        // The chunks across block boundaries first: lane j puts together the one that ends with the
+        // first c0 floats of block j (for j = 0 it begins in the last block of row t - 1).
+        float jv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane < N) {
+          const int j = lane, c0 = (4 - ((a + j) & 3)) & 3;
+          if (c0 > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int g = c0 - 4 + e;  // float index relative to the start of block j
+              const int tt = (g < 0 && j == 0) ? t - 1 : t;
+              const int blk = g < 0 ? (j == 0 ? N - 1 : j - 1) : j;
+              const int c = g < 0 ? g + B : g;
+              const int sc = min(max(tt + blk - hN, 0), nframes - 1);
+              jv[e] = ring_row(sc)[c];
+            }
+          }
+        }
+        // The row as a run of 16-byte chunks, 64 per instruction: chunk ch covers the row's floats
+        // 4 ch - a .. 4 ch - a + 3 and belongs to the row that holds its last float, so every store
+        // instruction writes 1 KiB without a gap.  A chunk inside one block is one aligned 16-byte LDS
+        // read of the source row; a chunk across two blocks comes from the lane that built it above.
+        const int ch_hi = ((int)W + a - 4) >> 2;
+        float* const obase = orow - a;  // 16-byte aligned
+        for (int ch0 = 0; ch0 <= ch_hi; ch0 += 64) {
+          const int ch = ch0 + lane;
+          const int g0 = 4 * min(ch, ch_hi) - a;  // lanes past the row's end repeat its last chunk (and do not store)
+          const int f = (int)(((unsigned)max(g0, 0) * 16321u) >> 22);  // g0 / 257 for 0 <= g0 < 2^15
+          const int c = g0 - f * B;
+          const bool across = g0 < 0 || c > B - 4;
+          const int jl = g0 < 0 ? 0 : f + 1;  // lane that holds a chunk across the boundary in front of block f + 1
+          const int su = t + f - hN, sc = min(max(su, 0), nframes - 1);
+          // phase of the source row + c is a multiple of four floats for every chunk that starts inside
+          // block f (a chunk across the boundary reads past bin 256 into the row's padding and is replaced
+          // below); the one chunk that starts in front of the row reads an aligned dummy
+          const float* const src = ring_row(sc) + (g0 < 0 ? 4 - a : c);
+          f32x4_t v;
+          if (interior) {
+            v = *(const f32x4_t*)__builtin_assume_aligned(src, 16);  // unclamped: the source row's phase is the block's
+          } else {
+            v = f32x4_t{src[0], src[1], src[2], src[3]};
+          }
+          const int ja = (across ? jl : lane) << 2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float w = lane_read(ja, jv[e]);
+            v[e] = across ? w : v[e];
+          }
+          if (ch <= ch_hi) {
+            if (t == 0 && ch == 0 && a > 0) {  // first row of the utterance: the floats in front belong to another utterance
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (e >= a) obase[e] = v[e];
+            } else {
+              *(f32x4_t*)__builtin_assume_aligned(obase + 4 * ch, 16) = v;
+            }
+          }
+        }
+        if (t == nframes - 1) {  // last row of the utterance: nobody follows to complete its last chunk
+          const int ntail = (a + 1) & 3;
+          if (lane < ntail) orow[W - ntail + lane] = ring_row(nframes - 1)[B - ntail + lane];
         }
       }
-      // Clamped windows: blocks f < h - t of the rows t < h take frame 0, blocks f > F - 1 - t + h of
-      // the last h rows take frame F - 1.  Their phase differs from the row's: single floats.
-      auto copy_any = [&](int i, int64_t dst) {
-        const int a = (int)((f_off + tb + i + hN) & 3);
-        const float* const src = xbuf + i * 512 + row_skew(i) + a;
-        float* const d = out_u + dst;
-        for (int c = lane; c < B; c += 64) d[c] = src[c];
-      };
-      if (tb == 0) {
-        int k = 0;
-        for (int t = 0; t < min(hN, nframes); ++t)
-          for (int f = 0; f < hN - t; ++f, ++k)
-            if ((k & 3) == wave) copy_any(0, (int64_t)t * W + (int64_t)f * B);
-      }
-      if (tb + nrow == nframes) {
-        int k = 0;
-        for (int t = max(0, nframes - hN); t < nframes; ++t)
-          for (int f = nframes - t + hN; f < N; ++f, ++k)
-            if ((k & 3) == wave) copy_any(nrow - 1, (int64_t)t * W + (int64_t)f * B);
-      }
+      stack_next = max(stack_next, t_end);
       if (more) delta = stage_st(tb + kBatch);
       __syncthreads();
       continue;

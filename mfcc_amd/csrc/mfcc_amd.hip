@@ -239,12 +239,19 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
   const bool c13 = plan->cfg.numcep == 13;
   // kernels with a compile-time numcep of 13 keep 13 floats per row of their statics ring, the others kMaxCep
   const bool ring13 = c13 && (out_kind == MFCC_OUT_MFCC39 || out_kind == MFCC_OUT_STATIC);
-  const size_t smem = mfcc::smem_floats(ring13 ? 13 : mfcc::kMaxCep) * sizeof(float) + MFCC_EXTRA_SMEM;
+  const bool stacked = out_kind == kLaunchSpecStack || out_kind == kLaunchLogspecStack;
+  const size_t smem = (stacked ? mfcc::smem_floats_stacked() : mfcc::smem_floats(ring13 ? 13 : mfcc::kMaxCep)) * sizeof(float) + MFCC_EXTRA_SMEM;
   const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
-#define MFCC_LAUNCH_G(OUT, NCEP, G)                                                                          \
-  do {                                                                                                       \
-    if (i16) hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, int16_t, G>), grid, block, smem, st, fp);     \
-    else hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, float, G>), grid, block, smem, st, fp);           \
+  // the stacked kinds take more than the 64 KiB of dynamic LDS a kernel gets without asking
+#define MFCC_LAUNCH_K(KERNEL)                                                                                              \
+  do {                                                                                                                     \
+    if (smem > 65536) (void)hipFuncSetAttribute((const void*)(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((KERNEL), grid, block, smem, st, fp);                                                               \
+  } while (0)
+#define MFCC_LAUNCH_G(OUT, NCEP, G)                                                 \
+  do {                                                                              \
+    if (i16) MFCC_LAUNCH_K((mfcc::fused_kernel<OUT, NCEP, int16_t, G>));            \
+    else MFCC_LAUNCH_K((mfcc::fused_kernel<OUT, NCEP, float, G>));                  \
   } while (0)
 #define MFCC_LAUNCH(OUT, NCEP)                                 \
   do {                                                         \
@@ -266,6 +273,7 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     case kLaunchSpecStack: MFCC_LAUNCH(mfcc::kOutSpecStack, 0); break;
     case kLaunchLogspecStack: MFCC_LAUNCH(mfcc::kOutLogspecStack, 0); break;
   }
+#undef MFCC_LAUNCH_K
 #undef MFCC_LAUNCH_G
 #undef MFCC_LAUNCH
 }
@@ -879,9 +887,9 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
     return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: out_kind must be MFCC_OUT_SPEC or MFCC_OUT_LOGSPEC");
   if (framenum < 1 || framenum % 2 == 0)
     return fail(MFCC_ERR_INVALID, "framenum=%d: use an odd number of frames (MLP_5hidlayer_40.py:261-262 warns the same)", framenum);
-  if (framenum % 4 != 1 || framenum > 65)
-    return fail(MFCC_ERR_UNSUPPORTED, "framenum=%d: the one-launch path takes framenum = 1, 5, 9, 13, 17, 21 ... 65 "
-                "(rows keep one 16-byte phase); use mfcc_forward + mfcc_stack_context", framenum);
+  if (framenum % 4 != 1 || framenum > mfcc::kStackMaxN)
+    return fail(MFCC_ERR_UNSUPPORTED, "framenum=%d: the one-launch path takes framenum = 1, 5, 9, 13, 17 (rows keep one 16-byte "
+                "phase, and the window has to fit the ring of spectrum rows in LDS); use mfcc_forward + mfcc_stack_context", framenum);
   if (layout->n_utts == 0 || layout->n_tiles == 0) return MFCC_OK;
   if (!out || !audio) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: null device pointer");
   if ((uintptr_t)out & 15) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: out must be 16-byte aligned");

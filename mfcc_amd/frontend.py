@@ -329,7 +329,7 @@ def spectrum_stack(fe, audio, layout, framenum, out=None, log=True):
     """The "257 coefficients x N frames" input of the MLP/CNN scripts (MLP_5hidlayer_40.py:244-248)
     straight from audio: spectrum rows of ``fe`` (ln of them when ``log``) stacked over ``framenum``
     frames with edge replication per utterance -> float32 [sum F, framenum * (nfft/2+1)].  One launch
-    when framenum % 4 == 1 (each 257-bin row is computed once and written framenum times); other odd
+    when framenum is 1, 5, 9, 13 or 17 (each 257-bin row is computed once and written framenum times); other odd
     values go through ``forward`` + ``stack_context``."""
     if not audio.is_cuda or not audio.is_contiguous() or audio.dtype not in (torch.int16, torch.float32):
         raise ValueError("audio must be a contiguous int16 or float32 device tensor")
@@ -338,7 +338,7 @@ def spectrum_stack(fe, audio, layout, framenum, out=None, log=True):
     framenum = int(framenum)
     width = fe.plan.out_width("spec")
     shape = (layout.total_frames, framenum * width)
-    if framenum % 4 != 1 or framenum > 65 or fe.plan.general or fe.plan.num_fft != 512:
+    if framenum % 4 != 1 or framenum > 17 or fe.plan.general or fe.plan.num_fft != 512:
         spec = fe.forward(audio, layout, kind="logspec" if log else "spec")
         return stack_context(spec, framenum, frame_counts=np.diff(layout.frame_offsets), out=out)
     if out is None:
