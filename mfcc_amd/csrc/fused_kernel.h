@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "fft_lane.h"
 
 // Issue priority of a wave per phase of the batch loop (s_setprio): the short filterbank / DCT
@@ -749,40 +751,70 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         // read of the source row; a chunk across two blocks comes from the lane that built it above.
         const int ch_hi = ((int)W + a - 4) >> 2;
         float* const obase = orow - a;  // 16-byte aligned
-        for (int ch0 = 0; ch0 <= ch_hi; ch0 += 64) {
-          const int ch = ch0 + lane;
-          const int g0 = 4 * min(ch, ch_hi) - a;  // lanes past the row's end repeat its last chunk (and do not store)
-          const int f = (int)(((unsigned)max(g0, 0) * 16321u) >> 22);  // g0 / 257 for 0 <= g0 < 2^15
-          const int c = g0 - f * B;
-          const bool across = g0 < 0 || c > B - 4;
-          const int jl = g0 < 0 ? 0 : f + 1;  // lane that holds a chunk across the boundary in front of block f + 1
-          const int su = t + f - hN, sc = min(max(su, 0), nframes - 1);
-          // phase of the source row + c is a multiple of four floats for every chunk that starts inside
-          // block f (a chunk across the boundary reads past bin 256 into the row's padding and is replaced
-          // below); the one chunk that starts in front of the row reads an aligned dummy
-          const float* const src = ring_row(sc) + (g0 < 0 ? 4 - a : c);
-          f32x4_t v;
-          if (interior) {
-            v = *(const f32x4_t*)__builtin_assume_aligned(src, 16);  // unclamped: the source row's phase is the block's
-          } else {
-            v = f32x4_t{src[0], src[1], src[2], src[3]};
-          }
-          const int ja = (across ? jl : lane) << 2;
+        // Four store instructions' worth of chunks at a time: their LDS reads are issued together, so
+        // a wave keeps several stores in flight.  Two copies of the loop -- rows whose window is not
+        // clamped (aligned 16-byte reads, no index clamps) and rows near the utterance's ends -- so
+        // that no branch sits between the reads (a branch makes the compiler wait for each one).
+        auto write_chunks = [&](auto interior_tag) {
+          constexpr bool kInterior = decltype(interior_tag)::value;
+          constexpr int U = 4;
+          for (int ch0 = 0; ch0 <= ch_hi; ch0 += 64 * U) {
+            f32x4_t v[U];
+            bool across[U];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float w = lane_read(ja, jv[e]);
-            v[e] = across ? w : v[e];
-          }
-          if (ch <= ch_hi) {
-            if (t == 0 && ch == 0 && a > 0) {  // first row of the utterance: the floats in front belong to another utterance
+            for (int u = 0; u < U; ++u) {
+              const int ch = ch0 + 64 * u + lane;
+              const int g0 = 4 * min(ch, ch_hi) - a;  // lanes past the row's end repeat its last chunk (and do not store)
+              const int f = (int)(__umul24((unsigned)max(g0, 0), 16321u) >> 22);  // g0 / 257 for 0 <= g0 < 2^15
+              const int c = g0 - f * B;
+              across[u] = g0 < 0 || c > B - 4;
+              // phase of the source row + c is a multiple of four floats for every chunk that starts inside
+              // block f (a chunk across the boundary reads past bin 256 into the row's padding and is replaced
+              // below); the one chunk that starts in front of the row reads an aligned dummy
+              const int cr = g0 < 0 ? 4 - a : c;
+#ifdef MFCC_ABL_ROWSRC
+              v[u] = f32x4_t{(float)f, jv[0], (float)c, 0.f};
+#else
+              if (kInterior) {  // unclamped: frame t + f - h, whose phase is the block's, (a + f) mod 4
+                const float* const src = sring + ((t + f - hN - s_lo) & (kSRingRows - 1)) * kSRingPitch + ((a + f) & 3) + cr;
+                v[u] = *(const f32x4_t*)__builtin_assume_aligned(src, 16);
+              } else {
+                const float* const src = ring_row(min(max(t + f - hN, 0), nframes - 1)) + cr;
+                v[u] = f32x4_t{src[0], src[1], src[2], src[3]};
+              }
+#endif
+            }
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (e >= a) obase[e] = v[e];
-            } else {
-              *(f32x4_t*)__builtin_assume_aligned(obase + 4 * ch, 16) = v;
+            for (int u = 0; u < U; ++u) {
+              const int chu = ch0 + 64 * u;  // wave-uniform: first chunk of this instruction
+              if (chu > ch_hi) break;
+              // 64 chunks span 256 floats, fewer than a block: at most one of them lies across a block
+              // boundary, the one in front of block jl (lane jl built it)
+              const int g_first = 4 * chu - a;
+              const int jl = g_first < 0 ? 0 : g_first / B + 1;
+#if !defined(MFCC_ABL_ROWSRC) && !defined(MFCC_ABL_ROWJ)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, jv[e]), jl));
+                v[u][e] = across[u] ? w : v[u][e];
+              }
+#endif
+              const int ch = chu + lane;
+              if (ch <= ch_hi) {
+                if (!kInterior && t == 0 && ch == 0 && a > 0) {  // first row of the utterance: the floats in front belong to another utterance
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    if (e >= a) obase[e] = v[u][e];
+                } else {
+                  *(f32x4_t*)__builtin_assume_aligned(obase + 4 * ch, 16) = v[u];
+                }
+              }
             }
           }
-        }
+        };
+        // a first row (t == 0) is never interior except for a window of one frame, which the clamped copy handles too
+        if (interior && t > 0) write_chunks(std::true_type{});
+        else write_chunks(std::false_type{});
         if (t == nframes - 1) {  // last row of the utterance: nobody follows to complete its last chunk
           const int ntail = (a + 1) & 3;
           if (lane < ntail) orow[W - ntail + lane] = ring_row(nframes - 1)[B - ntail + lane];
