@@ -204,6 +204,9 @@ def test_full_size_batch_properties(M):
     assert torch.isfinite(out).all()
     sub = fe(audio[4321:4325].contiguous())
     assert torch.equal(sub, out[4321 * 299:4325 * 299])
+    # the tiles left over after whole rounds of the grid (the last 16 of 10 000 on 3 x 256 places) are cut
+    # into shorter ones by the layout: same rows as when those utterances run alone, as whole tiles
+    assert torch.equal(fe(audio[9980:].contiguous()), out[9980 * 299:])
     for u in list(range(0, 10000, 769)) + [9999]:       # a strided sample of 15 utterances
         ref = O.mfcc39(audio[u].cpu().numpy(), "self5", loop=False)
         assert_cep(out[u * 299:(u + 1) * 299].cpu().numpy(), ref, f"utt {u}")
