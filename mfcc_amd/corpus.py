@@ -16,12 +16,14 @@ import torch
 from . import frontend as F
 
 
-def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None, ddof=0, events=None, static_scratch=False):
+def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None, ddof=0, events=None, static_scratch=False,
+                     per_chunk_sums=False):
     """fe: MFCC extractor; audio: this rank's packed device samples; lengths: its utterance
     lengths.  Returns (feats [sum F, D] normalised in place, sums float64[1 + 2 D] of the whole
     corpus, mm, vv).  ``events``: optional dict that receives per-phase lists of (start, end)
     torch.cuda.Event pairs recorded on the current stream (phases: forward, accumulate, exchange,
-    apply)."""
+    apply).  ``per_chunk_sums``: accumulate the statistics after every chunk (while its rows are still in
+    the caches) instead of in one pass after the last chunk."""
     lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
     plan = fe.plan
     counts = np.array([plan.frames_for_length(int(n)) for n in lengths], dtype=np.int64) if len(set(lengths.tolist())) > 1 \
@@ -54,11 +56,17 @@ def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None,
             e = mark("forward")
             fe.forward(audio[s_pos:s_pos + ns], lay, out=view)
             if e: e.record()
-            e = mark("accumulate")
-            F.cmvn_accumulate(view[:, :d], sums, static=static_scratch)
-            if e: e.record()
+            if per_chunk_sums:
+                e = mark("accumulate")
+                F.cmvn_accumulate(view[:, :d], sums, static=static_scratch)
+                if e: e.record()
             s_pos += ns
             f_pos += nf
+        if not per_chunk_sums:
+            # the rows are all resident: one pass over them (the extraction launches then run back to back)
+            e = mark("accumulate")
+            F.cmvn_accumulate(feats, sums, static=static_scratch)
+            if e: e.record()
         e = mark("exchange")
         F.cmvn_allreduce(sums, group=group)
         mm, vv = F.cmvn_constants(sums, ddof=ddof)
