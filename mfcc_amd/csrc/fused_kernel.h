@@ -172,6 +172,68 @@ struct PlanConst {
   int32_t decim;          // 1: 512-point plan; 2: 256-point plan = the even bins of the 512-point transform
 };
 
+// ---- streaming (B live streams in lock step, one workgroup per stream and push) ------------------
+constexpr int kStreamHalo = 2 * kHalo;  // static rows kept from earlier pushes (delta-delta reaches 4 back)
+
+struct StreamStep {
+  // audio segments: [2][B][cap] samples, statics: [2][B][rows][kMaxCep] floats (ping-pong halves)
+  int32_t n_streams, cap, rows;
+  int32_t src_half;      // half holding the previous segment / statics
+  int32_t src_skip;      // samples of the previous segment to drop from its front
+  int32_t keep;          // samples of the previous segment carried over
+  int32_t n_new;         // samples appended per stream
+  int32_t prev_new_rows; // static rows the previous step computed (its rows kStreamHalo .. +prev_new_rows)
+  int32_t t0, nt;        // first new frame (segment-relative) and number of new frames
+  int32_t tile_max;      // frames per tile of the fused kernel
+  int32_t tiles_per_stream;
+};
+
+// What the streaming kind of the fused kernel needs besides the step: the chunk to append and where
+// the finished rows go.  Frame numbers e0, lo, hi are relative to the first new static row.
+struct StreamArgs {
+  StreamStep step = {};
+  const void* chunk = nullptr;  // [B][chunk_ld] samples
+  int64_t chunk_ld = 0;
+  float* rows_out = nullptr;    // [B][out_stream_stride] floats, rows of out_ld
+  int64_t out_stream_stride = 0, out_ld = 0;
+  int32_t e0 = 0, k = 0;        // first row to emit, number of rows
+  int32_t lo = 0, hi = 0;       // frame range of the utterance known so far (clamp of the regression taps)
+};
+
+// New segment of stream b = [carried tail | chunk]; the last kStreamHalo static rows move to the
+// front of the other half.  Called by all 256 threads of one workgroup (or by several workgroups
+// that split the samples: i0 = first sample of the caller, stride = samples per sweep).
+template <typename T>
+__device__ __forceinline__ void stream_carry(const StreamStep& s, int b, T* seg, float* stat, const T* chunk, int64_t chunk_ld,
+                                             int i0, int stride, bool move_rows, int tid) {
+  const int dst_half = s.src_half ^ 1;
+  T* const dst = seg + ((int64_t)dst_half * s.n_streams + b) * s.cap;
+  const T* const src = seg + ((int64_t)s.src_half * s.n_streams + b) * s.cap + s.src_skip;
+  const int total = s.keep + s.n_new;
+  for (int i = i0; i < total; i += stride) dst[i] = i < s.keep ? src[i] : chunk[(int64_t)b * chunk_ld + (i - s.keep)];
+  if (move_rows) {
+    float* const sd = stat + ((int64_t)dst_half * s.n_streams + b) * s.rows * kMaxCep;
+    const float* const ss = stat + ((int64_t)s.src_half * s.n_streams + b) * s.rows * kMaxCep + s.prev_new_rows * kMaxCep;
+    for (int i = tid; i < kStreamHalo * kMaxCep; i += 256) sd[i] = ss[i];
+  }
+}
+
+// One output row element: [c | delta | delta-delta] of frame e for coefficient c, the regression of
+// mfcc-self5.py:169-179 applied twice.  S = the stream's static rows, row 0 = first new frame of
+// this step, column c; taps are clamped to [lo, hi]: lo = the utterance's frame 0, hi = its last
+// frame at flush (edge replication, mfcc-self5.py:174) or out of reach before.
+__device__ __forceinline__ void stream_emit_one(const float* S, int e, int lo, int hi, int ncep, int c, float* o) {
+  auto st = [&](int u) { return S[min(max(u, lo), hi) * kMaxCep]; };
+  auto reg = [](float a, float bb, float m, float d, float ee) { return (2.f * (ee - a) + (d - bb) + 0.f * m) * 0.1f; };
+  auto dl = [&](int v) {
+    v = min(max(v, lo), hi);
+    return reg(st(v - 2), st(v - 1), st(v), st(v + 1), st(v + 2));
+  };
+  o[c] = st(e);
+  o[ncep + c] = dl(e);
+  o[2 * ncep + c] = reg(dl(e - 2), dl(e - 1), dl(e), dl(e + 1), dl(e + 2));
+}
+
 struct FusedParams {
   const void* audio;
   int64_t total_elems;        // elements in `audio`, >= 1 (bounds the 16-byte staging loads)
@@ -183,6 +245,7 @@ struct FusedParams {
   int64_t out_ld;
   const PlanConst* pc;
   int32_t stack_n;            // stacked kinds: frames per context window N (N % 4 == 1); out_ld = N * bins
+  StreamArgs stream;          // streaming kind only
 #ifdef MFCC_DIAG
   unsigned long long* dbg;    // [n_tiles][4 waves][8] cycle sums
 #endif
@@ -197,7 +260,11 @@ struct FusedParams {
 #endif
 
 enum : int { kOutMfcc39 = 0, kOutStatic = 1, kOutLogmel = 2, kOutSpec = 3, kOutLogspec = 4,
-             kOutSpecStack = 5, kOutLogspecStack = 6 };  // spectrum rows stacked over N frames (context windows)
+             kOutSpecStack = 5, kOutLogspecStack = 6,    // spectrum rows stacked over N frames (context windows)
+             // One push of B live streams in one launch, workgroup b = stream b: append the chunk to the
+             // stream's segment, static rows of the new complete frames (as kOutStatic, into the stream's
+             // row store), then the output rows whose +-4-frame context is complete.
+             kOutStream = 7 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -384,11 +451,29 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const int fb = wave * 4 + g4;  // frame slot inside the batch
 
   const PlanConst* const pc = p.pc;
-  const Tile tile = p.tiles[blockIdx.x];
-  const int64_t s_off = p.sample_off[tile.utt];
-  const int64_t len = p.sample_len ? p.sample_len[tile.utt] : p.sample_off[tile.utt + 1] - s_off;
-  const int64_t f_off = p.frame_off[tile.utt];
-  const int nframes = (int)(p.frame_off[tile.utt + 1] - f_off);
+  Tile tile;
+  int64_t s_off, len, f_off;
+  int nframes;
+  if (OUT == kOutStream) {
+    // the step's layout follows from its scalars: segment and row store of stream b in the half
+    // this push writes; row (f_off + t) of the row store holds segment frame t
+    const StreamStep& ss = p.stream.step;
+    const int b = blockIdx.x;
+    stream_carry<T>(ss, b, (T*)const_cast<void*>(p.audio), p.out, (const T*)p.stream.chunk, p.stream.chunk_ld, tid, 256, true, tid);
+    __syncthreads();  // the segment is read back below by other waves of this workgroup
+    const int64_t slot = (int64_t)(ss.src_half ^ 1) * ss.n_streams + b;
+    tile = Tile{b, ss.t0, ss.nt, 0};
+    s_off = slot * ss.cap;
+    len = ss.keep + ss.n_new;
+    f_off = slot * ss.rows + kStreamHalo - ss.t0;
+    nframes = ss.t0 + ss.nt;
+  } else {
+    tile = p.tiles[blockIdx.x];
+    s_off = p.sample_off[tile.utt];
+    len = p.sample_len ? p.sample_len[tile.utt] : p.sample_off[tile.utt + 1] - s_off;
+    f_off = p.frame_off[tile.utt];
+    nframes = (int)(p.frame_off[tile.utt + 1] - f_off);
+  }
   const int t0 = tile.t0, nt = tile.nt;
   // frames this tile computes: its own, plus what the rows at its ends reach for where the utterance
   // continues (4 frames for delta-delta, half a context window for the stacked kinds)
@@ -971,6 +1056,18 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   dsum[6] = tk1 - tk0;
 #endif
 
+  if (OUT == kOutStream) {
+    // rows whose context is complete: all their static rows are in the row store now (this push's
+    // written above by this workgroup, the kStreamHalo before them carried over)
+    __syncthreads();
+    const StreamArgs& sa = p.stream;
+    const float* const S0 = p.out + (f_off + t0) * p.out_ld;  // first new static row of this stream
+    float* const ob = sa.rows_out + (int64_t)blockIdx.x * sa.out_stream_stride;
+    for (int idx = tid; idx < sa.k * kMaxCep; idx += 256) {
+      const int c = idx & (kMaxCep - 1), i = idx / kMaxCep;
+      if (c < ncep) stream_emit_one(S0 + c, sa.e0 + i, sa.lo, sa.hi, ncep, c, ob + (int64_t)i * sa.out_ld);
+    }
+  }
   if (OUT == kOutMfcc39) {
     // the rows still held back: from 4 rows before the last batch to the tile's end (at most 20)
     __syncthreads();

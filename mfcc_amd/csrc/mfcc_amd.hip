@@ -223,7 +223,7 @@ extern "C" void mfcc_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p;
 #endif
 
 // launch_fused selectors of the stacked spectrum kinds (not part of the public out_kind values)
-enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101 };
+enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101, kLaunchStream = 102 };
 
 // One workgroup per tile; template arguments select the output kind, a compile-time numcep of 13
 // where it pays, and the sample type.
@@ -238,7 +238,7 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
   }
   const bool c13 = plan->cfg.numcep == 13;
   // kernels with a compile-time numcep of 13 keep 13 floats per row of their statics ring, the others kMaxCep
-  const bool ring13 = c13 && (out_kind == MFCC_OUT_MFCC39 || out_kind == MFCC_OUT_STATIC);
+  const bool ring13 = c13 && (out_kind == MFCC_OUT_MFCC39 || out_kind == MFCC_OUT_STATIC || out_kind == kLaunchStream);
   const bool stacked = out_kind == kLaunchSpecStack || out_kind == kLaunchLogspecStack;
   const size_t smem = (stacked ? mfcc::smem_floats_stacked() : mfcc::smem_floats(ring13 ? 13 : mfcc::kMaxCep)) * sizeof(float) + MFCC_EXTRA_SMEM;
   const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
@@ -272,6 +272,10 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     case MFCC_OUT_LOGSPEC: MFCC_LAUNCH(mfcc::kOutLogspec, 0); break;
     case kLaunchSpecStack: MFCC_LAUNCH(mfcc::kOutSpecStack, 0); break;
     case kLaunchLogspecStack: MFCC_LAUNCH(mfcc::kOutLogspecStack, 0); break;
+    case kLaunchStream:
+      if (c13) MFCC_LAUNCH(mfcc::kOutStream, 13);
+      else MFCC_LAUNCH(mfcc::kOutStream, 0);
+      break;
   }
 #undef MFCC_LAUNCH_K
 #undef MFCC_LAUNCH_G
@@ -1245,6 +1249,52 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
   ss.tiles_per_stream = (ss.nt + s->tile_max - 1) / s->tile_max;
   if (ss.keep + n > s->cap || ss.nt > s->rows - mfcc::kStreamHalo || ss.tiles_per_stream > s->max_tiles)
     return fail(MFCC_ERR_INVALID, "mfcc_stream: internal capacity exceeded (keep %d, n %d, new frames %d)", ss.keep, n, ss.nt);
+  const int64_t k_rows = e_target - s->e_done;
+  // frame numbers of the rows to emit, relative to the first new static row (utterance frame f_done)
+  const int64_t big = 1 << 28;
+  const int32_t e0 = (int32_t)(s->e_done - s->f_done);
+  const int32_t lo = (int32_t)std::max(-s->f_done, -big);
+  const int32_t hi = last ? (int32_t)(f_target - 1 - s->f_done) : (int32_t)big;
+  const int32_t new_half = s->half ^ 1;
+  auto advance = [&]() {
+    s->half = new_half;
+    s->seg_start = start;
+    s->total += n;
+    s->prev_new_rows = ss.nt;
+    s->f_done = f_target;
+    s->e_done = e_target;
+  };
+  if (!plan->general && ss.tiles_per_stream <= 1) {
+    // the usual push (new frames fit one tile): one launch, workgroup b = stream b, does all three parts
+    mfcc::FusedParams fp;
+    fp.audio = s->seg;
+    fp.total_elems = (int64_t)2 * s->n_streams * s->cap;
+    fp.sample_off = nullptr;
+    fp.sample_len = nullptr;
+    fp.frame_off = nullptr;
+    fp.tiles = nullptr;
+    fp.out = s->stat;
+    fp.out_ld = mfcc::kMaxCep;
+    fp.pc = plan->pc;
+    fp.stack_n = 0;
+#ifdef MFCC_DIAG
+    fp.dbg = nullptr;
+#endif
+    fp.stream.step = ss;
+    fp.stream.chunk = chunk;
+    fp.stream.chunk_ld = chunk_ld;
+    fp.stream.rows_out = out;
+    fp.stream.out_stream_stride = out_stream_stride;
+    fp.stream.out_ld = out_ld;
+    fp.stream.e0 = e0;
+    fp.stream.k = (int32_t)std::max<int64_t>(k_rows, 0);
+    fp.stream.lo = lo;
+    fp.stream.hi = hi;
+    launch_fused(plan, fp, s->n_streams, kLaunchStream, s->dtype == MFCC_AUDIO_I16, st);
+    HIP_TRY(hipGetLastError());
+    advance();
+    return MFCC_OK;
+  }
   const int total = ss.keep + n;
   const dim3 agrid((unsigned)std::max(1, std::min(64, (total + 255) / 256)), (unsigned)s->n_streams);
   if (s->dtype == MFCC_AUDIO_I16)
@@ -1253,7 +1303,6 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
   else
     hipLaunchKernelGGL(mfcc::stream_append_kernel<float>, agrid, dim3(256), 0, st, ss, (float*)s->seg, s->stat,
                        (const float*)chunk, chunk_ld, s->d_sample_off, s->d_sample_len, s->d_frame_off, s->d_tiles);
-  const int32_t new_half = s->half ^ 1;
   if (ss.nt > 0) {
     mfcc::FusedParams fp;
     fp.audio = s->seg;
@@ -1271,24 +1320,14 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
 #endif
     launch_fused(plan, fp, (int64_t)s->n_streams * ss.tiles_per_stream, MFCC_OUT_STATIC, s->dtype == MFCC_AUDIO_I16, st);
   }
-  const int64_t k = e_target - s->e_done;
+  const int64_t k = k_rows;
   if (k > 0) {
-    // frame numbers relative to the first new static row (utterance frame f_done)
-    const int64_t big = 1 << 28;
-    const int32_t e0 = (int32_t)(s->e_done - s->f_done);
-    const int32_t lo = (int32_t)std::max(-s->f_done, -big);
-    const int32_t hi = last ? (int32_t)(f_target - 1 - s->f_done) : (int32_t)big;
     const int64_t work = (int64_t)s->n_streams * k * mfcc::kMaxCep;
     hipLaunchKernelGGL(mfcc::stream_emit_kernel, dim3(blocks_for(work, 256)), dim3(256), 0, st, s->stat, new_half, s->n_streams,
                        s->rows, e0, (int32_t)k, lo, hi, plan->cfg.numcep, out, out_stream_stride, out_ld);
   }
   HIP_TRY(hipGetLastError());
-  s->half = new_half;
-  s->seg_start = start;
-  s->total += n;
-  s->prev_new_rows = ss.nt;
-  s->f_done = f_target;
-  s->e_done = e_target;
+  advance();
   return MFCC_OK;
 }
 

@@ -14,21 +14,6 @@
 
 namespace mfcc {
 
-constexpr int kStreamHalo = 2 * kHalo;  // static rows kept from earlier pushes (delta-delta reaches 4 back)
-
-struct StreamStep {
-  // audio segments: [2][B][cap] samples, statics: [2][B][rows][kMaxCep] floats (ping-pong halves)
-  int32_t n_streams, cap, rows;
-  int32_t src_half;      // half holding the previous segment / statics
-  int32_t src_skip;      // samples of the previous segment to drop from its front
-  int32_t keep;          // samples of the previous segment carried over
-  int32_t n_new;         // samples appended per stream
-  int32_t prev_new_rows; // static rows the previous step computed (its rows kStreamHalo .. +prev_new_rows)
-  int32_t t0, nt;        // first new frame (segment-relative) and number of new frames
-  int32_t tile_max;      // frames per tile of the fused kernel
-  int32_t tiles_per_stream;
-};
-
 // One launch per push: (1) new segment = [carried tail | chunk], (2) the last kStreamHalo static
 // rows move to the front of the other half, (3) the per-step layout of the fused kernel
 // (offsets, lengths, tiles) is written from the scalars above -- no host-to-device copy.
@@ -38,15 +23,9 @@ __global__ void __launch_bounds__(256) stream_append_kernel(const StreamStep s, 
                                                             int64_t* frame_off, Tile* tiles) {
   const int b = blockIdx.y;
   const int dst_half = s.src_half ^ 1;
-  T* const dst = seg + ((int64_t)dst_half * s.n_streams + b) * s.cap;
-  const T* const src = seg + ((int64_t)s.src_half * s.n_streams + b) * s.cap + s.src_skip;
   const int total = s.keep + s.n_new;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256)
-    dst[i] = i < s.keep ? src[i] : chunk[(int64_t)b * chunk_ld + (i - s.keep)];
+  stream_carry<T>(s, b, seg, stat, chunk, chunk_ld, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, blockIdx.x == 0, threadIdx.x);
   if (blockIdx.x == 0) {
-    float* const sd = stat + ((int64_t)dst_half * s.n_streams + b) * s.rows * kMaxCep;
-    const float* const ss = stat + ((int64_t)s.src_half * s.n_streams + b) * s.rows * kMaxCep + s.prev_new_rows * kMaxCep;
-    for (int i = threadIdx.x; i < kStreamHalo * kMaxCep; i += 256) sd[i] = ss[i];
     if (threadIdx.x == 0) {
       sample_off[b] = ((int64_t)dst_half * s.n_streams + b) * s.cap;
       sample_len[b] = total;
@@ -80,17 +59,7 @@ __global__ void __launch_bounds__(256) stream_emit_kernel(const float* stat, int
   const int b = idx / (kMaxCep * k);
   if (b >= n_streams || c >= ncep) return;
   const float* const S = stat + (((int64_t)half * n_streams + b) * rows + kStreamHalo) * kMaxCep + c;
-  auto st = [&](int u) { return S[min(max(u, lo), hi) * kMaxCep]; };
-  auto reg = [](float a, float bb, float m, float d, float e) { return (2.f * (e - a) + (d - bb) + 0.f * m) * 0.1f; };
-  auto dl = [&](int v) {
-    v = min(max(v, lo), hi);
-    return reg(st(v - 2), st(v - 1), st(v), st(v + 1), st(v + 2));
-  };
-  const int e = e0 + i;
-  float* const o = out + b * out_stream_stride + i * out_ld;
-  o[c] = st(e);
-  o[ncep + c] = dl(e);
-  o[2 * ncep + c] = reg(dl(e - 2), dl(e - 1), dl(e), dl(e + 1), dl(e + 2));
+  stream_emit_one(S, e0 + i, lo, hi, ncep, c, out + b * out_stream_stride + i * out_ld);
 }
 
 }  // namespace mfcc
