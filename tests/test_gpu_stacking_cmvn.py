@@ -264,3 +264,38 @@ def test_spectrum_stack_one_launch_equals_two_kernels(M, variant, log):
         assert (np.abs(got - ref) <= 2e-6 * np.abs(ref).max()).all()
     with pytest.raises(ValueError):
         M.spectrum_stack(fe, packed, lay, 17, out=torch.empty(3, 3, device="cuda"))
+
+
+def test_spectrum_stack_other_instantiations(M):
+    """The row writer of mfcc_forward_stacked for the other window lengths, float32 samples, the 200/80-sample
+    framing with a 512-point FFT, a Hamming window, and a batch large enough that the layout cuts its last
+    tiles short: always bit-equal to mfcc_forward + mfcc_stack_context."""
+    rng = np.random.default_rng(5)
+    frames = [33, 1, 7, 16, 299, 100, 17, 2, 640]
+    lengths = [400 + 160 * (f - 1) - int(rng.integers(0, 160)) if f > 1 else 77 for f in frames]
+    audio = np.concatenate([np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths])
+    for kw, samples in ((dict(), torch.from_numpy(audio).cuda()),
+                        (dict(), torch.from_numpy(audio.astype(np.float32) / 32768).cuda()),
+                        (dict(window="hamming"), torch.from_numpy(audio).cuda())):
+        fe = M.MFCC("self5", **kw)
+        lay = fe.layout(lengths)
+        spec = fe.forward(samples, lay, kind="logspec")
+        counts = np.diff(lay.frame_offsets)
+        for framenum in (9, 13, 17):
+            assert torch.equal(M.spectrum_stack(fe, samples, lay, framenum), M.stack_context(spec, framenum, frame_counts=counts))
+    # 25 ms / 10 ms at 8 kHz with the 512-point FFT of the CTC scripts: 200/80-sample frames on the specialised kernel
+    fe8 = M.MFCC("self5", fs=8000, num_fft=512)
+    assert not fe8.plan.general
+    l8 = [200 + 80 * (f - 1) - int(rng.integers(0, 80)) if f > 1 else 50 for f in frames]
+    a8 = torch.from_numpy(np.concatenate([np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in l8])).cuda()
+    lay8 = fe8.layout(l8)
+    assert list(np.diff(lay8.frame_offsets)) == frames
+    spec8 = fe8.forward(a8, lay8, kind="spec")
+    assert torch.equal(M.spectrum_stack(fe8, a8, lay8, 17, log=False), M.stack_context(spec8, 17, frame_counts=frames))
+    # 800 equal utterances: 32 tiles beyond one round of 3 x 256 workgroups are cut into short ones
+    fe = M.MFCC("self15")
+    n_utt, n_len = 800, 16000
+    big = (torch.randn(n_utt * n_len, device="cuda") * 3000).clamp(-32768, 32767).to(torch.int16)
+    layb = fe.layout([n_len] * n_utt)
+    specb = fe.forward(big, layb, kind="spec")
+    assert torch.equal(M.spectrum_stack(fe, big, layb, 17, log=False), M.stack_context(specb, 17, frame_counts=np.diff(layb.frame_offsets)))
