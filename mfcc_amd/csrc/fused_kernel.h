@@ -157,8 +157,9 @@ struct MelMap {
 struct PlanConst {
   const float* tw512;     // [512][2]  exp(-2 pi i m / 512)
   const float* melB;      // [4][kMelSteps/4][64][4] B operands (filter weights * spec_scale): 16 B per lane and 4 k-steps
-  const float* dctA;      // [4 waves][64][4] per-wave DCT*lifter weights of the chained product: lane (c = lane & 15,
-                          //   g = lane >> 4), element r = weight of (filter first_filter[w] + g + 4 r, coefficient c)
+  const float* dctA;      // [4 waves][64][4] per-wave DCT*lifter weights of the chained product, times ln 2 (the kernel
+                          //   feeds it log2 of the mel sums): lane (c = lane & 15, g = lane >> 4), element r = weight of
+                          //   (filter first_filter[w] + g + 4 r, coefficient c)
   const float* window;    // [512] or nullptr
   MelMap map;
   int32_t mel_steps[4];   // k-steps wave w really needs (<= kMelSteps)
@@ -548,11 +549,24 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     const bool interior = r_wave >= kHalo && r_wave + 3 + kHalo <= nframes - 1;
     float v[9], d[5];
     if (interior) {
+      // two regressions per packed instruction: the rows are read once as the pairs (v0,v1) .. (v6,v7)
+      // and once more as (v1,v2) .. (v7,v8); same operations in the same order as regress()
       const float* const w0 = ring + ((r - kHalo - s_lo + 8) & 31) * RP + q;
+      cf pe[4], po[4];
 #pragma unroll
-      for (int m = 0; m < 9; ++m) v[m] = w0[m * RP];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) d[k] = regress(v[k], v[k + 1], v[k + 2], v[k + 3], v[k + 4]);
+      for (int m = 0; m < 4; ++m) {
+        pe[m] = mk(w0[2 * m * RP], w0[(2 * m + 1) * RP]);
+        po[m] = mk(w0[(2 * m + 1) * RP], w0[(2 * m + 2) * RP]);
+      }
+      const cf two = mk(2.f, 2.f), zero = mk(0.f, 0.f), tenth = mk(0.1f, 0.1f);
+      auto regress2 = [&](cf a, cf b, cf m, cf dd, cf e) {
+        return __builtin_elementwise_fma(zero, m, __builtin_elementwise_fma(two, e - a, dd - b)) * tenth;
+      };
+      const cf d01 = regress2(pe[0], po[0], pe[1], po[1], pe[2]);  // rows k = 0, 1: taps k .. k + 4
+      const cf d23 = regress2(pe[1], po[1], pe[2], po[2], pe[3]);
+      v[4] = pe[2].x;
+      d[0] = d01.x; d[1] = d01.y; d[2] = d23.x; d[3] = d23.y;
+      d[4] = regress(pe[2].x, pe[2].y, pe[3].x, pe[3].y, po[3].y);
     } else {
       asm volatile("" ::: "memory");  // keeps this rare path a real branch: nothing of it is hoisted
 #pragma unroll
@@ -974,8 +988,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
         for (int r = 0; r < 4; ++r) mv[r] = mv[r] == 0.f ? kEps64 : mv[r];
       }
+      // ln for the ln-mel output; the chained DCT takes log2 (its weights carry the factor ln 2)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lm[r] = g4 + 4 * r < mel_nf ? fast_ln(mv[r]) : 0.f;
+      for (int r = 0; r < 4; ++r) lm[r] = g4 + 4 * r < mel_nf ? (OUT == kOutLogmel ? fast_ln(mv[r]) : __builtin_amdgcn_logf(mv[r])) : 0.f;
       float* const tile_w = part + wave * kPartTile;
       if (g4 == 3) tile_w[((q >> 2) * kPartSlots + 16) * 4 + (q & 3)] = acc[3];
       if (OUT == kOutLogmel) {

@@ -458,7 +458,7 @@ static int build_specialised(mfcc_plan* p) {
       for (int r = 0; r < 4; ++r) {
         const int c = lane & 15, j = (lane >> 4) + 4 * r;
         if (j < pmap.nfilt[g] && c < cfg->numcep)
-          dctA[((size_t)g * 64 + lane) * 4 + r] = (float)dl[(size_t)(pmap.first_filter[g] + j) * cfg->numcep + c];
+          dctA[((size_t)g * 64 + lane) * 4 + r] = (float)(dl[(size_t)(pmap.first_filter[g] + j) * cfg->numcep + c] * M_LN2);  // the kernel hands over log2 of the mel sums
       }
   std::vector<float> win;
   if (cfg->window == MFCC_WINDOW_HAMMING) {
