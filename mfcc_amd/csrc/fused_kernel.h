@@ -745,6 +745,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           const float4 v0 = tv[0], v1 = tv[1];
           pw[0] = mk(v0.x, v0.y); pw[1] = mk(v0.z, v0.w); pw[2] = mk(v1.x, v1.y); pw[3] = mk(v1.z, v1.w);
         }
+        float lo4[4], hi4[4];  // MFCC kinds: the group's eight values, stored together below
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           if (q == 0) pb[s] = x[(16 - h - s) & 15];  // lane 0 pairs inside itself: Z[16 s] with Z[16 (16 - s)]
@@ -771,8 +772,25 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
               }
             }
           } else {
-            P[q + 16 * (h + s)] = lo;
-            P[256 - q - 16 * (h + s)] = hi;
+            lo4[s] = lo;
+            hi4[s] = hi;
+          }
+        }
+        if (!kSpecOut) {
+          if (mag) {
+            // magnitude spectrum (mfcc-self15.py:234): one branch per group, so that the power path
+            // does not pay for the square roots
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              lo4[s] = __builtin_amdgcn_sqrtf(lo4[s]);
+              hi4[s] = __builtin_amdgcn_sqrtf(hi4[s]);
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            P[q + 16 * (h + s)] = lo4[s];
+            P[256 - q - 16 * (h + s)] = hi4[s];
           }
         }
       }
@@ -782,17 +800,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         } else if (kSpecOut) {
           if (spec_row) spec_row[half_band ? 64 : 128] = spec_value(4.f * norm2(x[8]));
         } else {
-          P[128] = 4.f * norm2(x[8]);
+          const float p128 = 4.f * norm2(x[8]);
+          P[128] = mag ? __builtin_amdgcn_sqrtf(p128) : p128;
           P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-steps
         }
-      }
-      if (mag && !kSpecOut) {
-        // magnitude spectrum (mfcc-self15.py:234): a pass of its own over the row, so that the
-        // power path does not pay for the square roots
-        wave_sync();
-#pragma unroll
-        for (int s = 0; s < 16; ++s) P[q + 16 * s] = __builtin_amdgcn_sqrtf(P[q + 16 * s]);
-        if (q == 0) P[256] = __builtin_amdgcn_sqrtf(P[256]);
       }
     }
 #if !defined(MFCC_ABL_STAGE) && defined(MFCC_EARLY_STAGE)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--utts", type=int, default=10000)
     ap.add_argument("--kind", default="mfcc39")
+    ap.add_argument("--variant", default="self5")
     ap.add_argument("--lib", action="append", default=[])
     args = ap.parse_args()
     import torch
@@ -39,7 +40,7 @@ def main():
         capi._lib = None
         capi.LIB_PATH = os.path.abspath(path)
         F._plan_cache.clear()
-        fe = F.MFCC("self5")
+        fe = F.MFCC(args.variant)
         lay = fe.layout([48000] * args.utts)
         out = torch.empty((lay.total_frames, fe.plan.out_width(args.kind)), dtype=torch.float32, device="cuda")
         fe.forward(flat, lay, out=out, kind=args.kind)
