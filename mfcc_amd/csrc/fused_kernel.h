@@ -488,6 +488,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const out_t0 = p.out + (f_off + t0) * p.out_ld;  // row t0 of this tile; 32-bit offsets from here
   const float pre_hi = pc->pre_hi, pre_lo = pc->pre_lo;
   const bool mag = pc->spectrum != 0;
+  // plan constants of the spectrum kinds, read here, before any store of the kernel: inside the batch
+  // loop they would be vector loads behind the staging loads on the in-order memory counter
+  const float spec_scale = kSpecOut ? pc->spec_scale : 0.f, spec_floor = kSpecOut ? pc->log_floor : 0.f;
+  const bool half_band = kSpecOut && pc->decim == 2;
   const gfloat_ptr window = as_global(pc->window);
   // this wave's share of the filterbank product
   const int mel_k0 = pc->map.kstart[wave], mel_nf = pc->map.nfilt[wave], mel_ff = pc->map.first_filter[wave];
@@ -600,6 +604,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   for (int tb = s_lo; tb < s_hi; tb += kBatch) {
     MFCC_STAMP(ta);
     __builtin_amdgcn_s_setprio(MFCC_PRIO_FFT);
+    // spectrum kinds have no filterbank phase to cover the staging loads of the next batch: they fly
+    // during this batch's transforms instead
+    if (kSpecOut && !kStack) stage_ld(tb + kBatch);
     float bv[kMelSteps];  // B operands of this wave's filterbank k-steps, fetched at the end of the FFT section
     // ---- FFT-512 of 4 frames per wave, 16 lanes per frame -----------------------------
     {
@@ -725,8 +732,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
                               : xbuf + fb * 512 + row_skew(fb);
       // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
       float* const spec_row = (kSpecOut && !kStack && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
-      const float spec_scale = kSpecOut ? pc->spec_scale : 0.f, spec_floor = kSpecOut ? pc->log_floor : 0.f;
-      const bool half_band = kSpecOut && pc->decim == 2;
       auto spec_value = [&](float p4) {
         // LDS rows would hold 4|X|^2 (power) or, after the square root, 2|X| (magnitude)
         float v = (mag ? __builtin_amdgcn_sqrtf(p4) : p4) * spec_scale;
@@ -936,8 +941,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       continue;
     }
     if (kSpecOut) {
-      // rows are already written; the barrier above only released the staged audio
-      stage_ld(tb + kBatch);
+      // rows are already written (from registers, in the untangle step); the barrier above only released
+      // the staged audio.  The loads of the next batch's samples were issued before this batch's
+      // transforms: they are older than the row stores, so consuming them does not wait for stores (the
+      // memory counter is in order), and the stores stay in flight across the barrier.
       if (more) delta = stage_st(tb + kBatch);
       __syncthreads();
       continue;
