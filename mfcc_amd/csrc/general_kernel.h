@@ -79,7 +79,9 @@ __device__ __forceinline__ float preemph_at(const T* __restrict__ x, int64_t g, 
   return __fsub_rn(x0, __fmul_rn(pre_hi, x1));
 }
 
-template <typename T>
+// TABLES_IN_LDS: the plan found room for the filter weights and the DCT matrix in LDS (both or
+// neither); a compile-time choice so that their reads are LDS or global instructions, not flat ones.
+template <typename T, bool TABLES_IN_LDS>
 __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const GeneralConst* __restrict__ gcp, int out_kind) {
   extern __shared__ __attribute__((aligned(16))) float gsm[];
   const GeneralConst gc = *gcp;
@@ -88,8 +90,11 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
   const int nmel = gc.nmel, ncep = gc.numcep, pf = gc.pad_fac;
   const cf* const twl = (const cf*)gsm;                   // [M] exp(-2 pi i k / nfft): read by every butterfly, so kept in LDS
   float* const tables = gsm + gc.nfft;                    // [bankc_lds] filter weights, [dct_lds] DCT * lifter
-  const float* const bankw = gc.bankc_lds ? tables : gc.bankc;
-  const float* const dctw = gc.dct_lds ? tables + gc.bankc_lds : gc.dctl;
+  typedef const float __attribute__((address_space(3))) * lds_cptr;
+  typedef const float __attribute__((address_space(1))) * glb_cptr;
+  typedef typename std::conditional<TABLES_IN_LDS, lds_cptr, glb_cptr>::type tab_cptr;
+  const tab_cptr bankw = TABLES_IN_LDS ? (tab_cptr)(uintptr_t)(lds_cptr)tables : (tab_cptr)(uintptr_t)gc.bankc;
+  const tab_cptr dctw = TABLES_IN_LDS ? (tab_cptr)(uintptr_t)(lds_cptr)(tables + gc.bankc_lds) : (tab_cptr)(uintptr_t)gc.dctl;
   float* const wbase = tables + gc.bankc_lds + gc.dct_lds + wave * general_wave_floats(gc.nfft, nmel);
   cf* const z = (cf*)wbase;                               // [M] complex
   float* const srow = wbase + gc.nfft;                    // [nbin] spectrum row
@@ -127,20 +132,45 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
   for (int t = s_lo + wave; t < s_hi; t += 4) {
     // ---- framing (mfcc-self5.py:85-95): samples t*step .. +frame_size, zeros past the utterance end
     const int64_t g0 = (int64_t)t * gc.frame_step;
-    for (int n = lane; n < M; n += 64) {
-      float v[2];
+    // Four complex points per lane and step, all their loads issued before the first is used (a load
+    // per point and a wait per point costs a memory round trip per 64 points).  Indices are clamped
+    // into the utterance so that every load is legal; what lies outside is zeroed below.
+    const bool pre_on = !(gc.pre_hi == 0.f && gc.pre_lo == 0.f);
+    for (int n0 = 0; n0 < M; n0 += 256) {
+      float xm[4], xa[4], xb[4], wa[4], wb[4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int i = 2 * n + j;
-        const int64_t g = g0 + i;
-        float y = 0.f;
-        if (i < gc.used && g < len) {
-          y = preemph_at(x, g, gc.pre_hi, gc.pre_lo);
-          if (gc.window) y *= gc.window[i];
-        }
-        v[j] = y;
+      for (int u = 0; u < 4; ++u) {
+        const int64_t g = g0 + 2 * (n0 + 64 * u + lane);
+        const int64_t hi = len - 1;
+        xm[u] = (float)x[g - 1 < 0 ? 0 : (g - 1 > hi ? hi : g - 1)];
+        xa[u] = (float)x[g > hi ? hi : g];
+        xb[u] = (float)x[g + 1 > hi ? hi : g + 1];
+        wa[u] = wb[u] = 1.f;
       }
-      z[bit_reverse((unsigned)n, gc.log2m)] = mk(v[0], v[1]);
+      if (gc.window) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = 2 * (n0 + 64 * u + lane);
+          wa[u] = gc.window[min(i, gc.frame_size - 1)];
+          wb[u] = gc.window[min(i + 1, gc.frame_size - 1)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + 64 * u + lane;
+        if (n >= M) break;
+        const int i = 2 * n;
+        const int64_t g = g0 + i;
+        // y[0] = x[0], y[n] = x[n] - c x[n-1] (mfcc-self5.py:68), two-term coefficient for int16 samples
+        auto emph = [&](float cur, float prev, bool first) {
+          if (first || !pre_on) return cur;
+          if (sizeof(T) == 2) return fmaf(-gc.pre_lo, prev, fmaf(-gc.pre_hi, prev, cur));
+          return __fsub_rn(cur, __fmul_rn(gc.pre_hi, prev));
+        };
+        const float y0 = (i < gc.used && g < len) ? emph(xa[u], xm[u], g == 0) * wa[u] : 0.f;
+        const float y1 = (i + 1 < gc.used && g + 1 < len) ? emph(xb[u], xa[u], false) * wb[u] : 0.f;
+        z[bit_reverse((unsigned)n, gc.log2m)] = mk(y0, y1);
+      }
     }
     wave_sync();
     // ---- nfft/2-point complex FFT, radix-2 decimation in time, in place
@@ -193,7 +223,7 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
       const int j = lane + 64 * u;
       if (j >= nmel) break;
       const int lo = blo[u], hi = bhi[u];
-      const float* const w = bankw + boff[u] - lo;  // w[k] = weight of bin k, lo <= k < hi
+      const tab_cptr w = bankw + boff[u] - lo;  // w[k] = weight of bin k, lo <= k < hi
       float acc = 0.f;
       int k = lo;
       for (; k + 4 <= hi; k += 4) {  // four weights in flight; the sum keeps the order of the bins

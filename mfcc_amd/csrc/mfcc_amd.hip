@@ -232,8 +232,14 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
   const dim3 grid((unsigned)n_tiles), block(256);
   if (plan->general) {
     // the public out_kind values are the kernel's own
-    if (i16) hipLaunchKernelGGL(mfcc::general_kernel<int16_t>, grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
-    else hipLaunchKernelGGL(mfcc::general_kernel<float>, grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+    const bool lds_tables = plan->gc_host.bankc_lds > 0 && plan->gc_host.dct_lds > 0;
+    if (lds_tables) {
+      if (i16) hipLaunchKernelGGL((mfcc::general_kernel<int16_t, true>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+      else hipLaunchKernelGGL((mfcc::general_kernel<float, true>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+    } else {
+      if (i16) hipLaunchKernelGGL((mfcc::general_kernel<int16_t, false>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+      else hipLaunchKernelGGL((mfcc::general_kernel<float, false>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+    }
     return;
   }
   const bool c13 = plan->cfg.numcep == 13;
@@ -519,8 +525,11 @@ static int build_general(mfcc_plan* p) {
   int bank_lds = 0, dct_lds = 0;
   const size_t bank_pad = (bankc.size() + 3) & ~(size_t)3, dct_pad = ((size_t)nmel * ncep + 3) & ~(size_t)3;
   bankc.resize(bank_pad, 0.f);  // the kernel copies whole 16-byte pieces
-  if (fixed_bytes + (table_floats + bank_pad) * sizeof(float) + want_rows * row_bytes <= 65536) { bank_lds = 1; table_floats += bank_pad; }
-  if (fixed_bytes + (table_floats + dct_pad) * sizeof(float) + want_rows * row_bytes <= 65536) { dct_lds = 1; table_floats += dct_pad; }
+  // both or neither: the kernel is compiled once for tables in LDS and once for tables in global memory
+  if (fixed_bytes + (bank_pad + dct_pad) * sizeof(float) + want_rows * row_bytes <= 65536) {
+    bank_lds = dct_lds = 1;
+    table_floats = bank_pad + dct_pad;
+  }
   const int64_t rows_fit = ((int64_t)65536 - (int64_t)fixed_bytes - (int64_t)(table_floats * sizeof(float))) / (int64_t)row_bytes;
   const int rows = (int)std::min<int64_t>(rows_fit, mfcc::kGenMaxTile + 4 * pf);
   if (rows - 4 * pf < 4)
