@@ -435,7 +435,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   extern __shared__ __attribute__((aligned(128))) float smem[];
   float* const xbuf = smem;
   float* const abuf = xbuf + kXbufFloats;
-  constexpr int RP = NCEP > 0 ? NCEP : kMaxCep;  // floats per row of the statics ring
+  // floats per row of the statics ring; only the MFCC-39 kind has one (the others would carry 2.5 KB
+  // of LDS they never touch, one allocation unit too many for three workgroups per CU)
+  constexpr int RP = OUT == kOutMfcc39 ? (NCEP > 0 ? NCEP : kMaxCep) : 0;
   constexpr bool kStack = (OUT == kOutSpecStack || OUT == kOutLogspecStack);
   float* const part = abuf + kAbufFloats;
   float* const ring = part + kPartFloats;

@@ -243,10 +243,10 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     return;
   }
   const bool c13 = plan->cfg.numcep == 13;
-  // kernels with a compile-time numcep of 13 keep 13 floats per row of their statics ring, the others kMaxCep
-  const bool ring13 = c13 && (out_kind == MFCC_OUT_MFCC39 || out_kind == MFCC_OUT_STATIC || out_kind == kLaunchStream);
+  // only the MFCC-39 kind keeps a ring of static rows in LDS: 13 floats per row where numcep is a compile-time 13
+  const int ring_pitch = out_kind == MFCC_OUT_MFCC39 ? (c13 ? 13 : mfcc::kMaxCep) : 0;
   const bool stacked = out_kind == kLaunchSpecStack || out_kind == kLaunchLogspecStack;
-  const size_t smem = (stacked ? mfcc::smem_floats_stacked() : mfcc::smem_floats(ring13 ? 13 : mfcc::kMaxCep)) * sizeof(float) + MFCC_EXTRA_SMEM;
+  const size_t smem = (stacked ? mfcc::smem_floats_stacked() : mfcc::smem_floats(ring_pitch)) * sizeof(float) + MFCC_EXTRA_SMEM;
   const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
   // the stacked kinds take more than the 64 KiB of dynamic LDS a kernel gets without asking
 #define MFCC_LAUNCH_K(KERNEL)                                                                                              \
