@@ -104,13 +104,16 @@ constexpr int kPartFloats = 4 * kPartTile;
 // ring row (t - s_lo + 8) mod 32; ring rows 0..7 are mirrored at 32..39 so that the 9 rows
 // t-4 .. t+4 a lane reads are always consecutive.
 constexpr int kRingRows = 40;
+// Kernels with a run-time numcep keep kMaxCep floats per ring row; 32 rows of those fill the same LDS
+// as 40 rows of 13, so they do without the mirror rows and wrap every row index instead.
+constexpr int ring_rows(int ring_pitch) { return ring_pitch > 13 ? 32 : kRingRows; }
 // per-lane-index twiddle row: 8 untangle values, then 15 stage-1 values, read 16 bytes at a time;
 // 52 q mod 64 are 16 distinct multiples of 4, so the 16 rows a read touches cover all 64 banks
 constexpr int kTwPitch = 52;
 constexpr int kTwUnt = 0, kTwSt1 = 8;                // complex index of the first untangle / stage-1 value
 constexpr int kTwFloats = 16 * kTwPitch;
 // ring_pitch = floats per ring row: numcep where it is a compile-time constant, else kMaxCep
-constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + kPartFloats + kRingRows * ring_pitch + kTwFloats; }
+constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + kPartFloats + ring_rows(ring_pitch) * ring_pitch + kTwFloats; }
 // Stacked spectrum kinds: instead of the partial-DCT tiles and the statics ring, a ring of the last
 // 32 spectrum rows (frame s of the tile at ring row (s - s_lo) mod 32, 257 values behind a phase of
 // 0..3 floats), from which whole output rows are written.  81 632 bytes: two workgroups per CU
@@ -123,7 +126,7 @@ static_assert(smem_floats_stacked() * 4 <= 64 * 1280, "stacked kinds no longer f
 static_assert(2 * (kStackMaxN / 2) + kBatch <= kSRingRows, "spectrum ring too short for the context window");
 // gfx950 hands out LDS in units of 1280 bytes; three workgroups per CU fit while each takes at
 // most 42 units of the CU's 128.  The 13-coefficient kernels meet that exactly.
-static_assert(smem_floats(13) * 4 <= 42 * 1280, "LDS carve no longer allows three workgroups per CU");
+static_assert(smem_floats(13) * 4 <= 42 * 1280 && smem_floats(kMaxCep) * 4 <= 42 * 1280, "LDS carve no longer allows three workgroups per CU");
 static_assert(kMelCols == 15, "filter slot 15 of a wave carries its energy partial");
 static_assert((kBatch - 1) * 512 + row_skew(kBatch - 1) + kRowPad <= kXbufFloats, "spectrum rows fit in the exchange buffer");
 
@@ -442,7 +445,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const part = abuf + kAbufFloats;
   float* const ring = part + kPartFloats;
   float* const sring = abuf + kAbufFloats;  // stacked kinds: ring of spectrum rows in place of part / ring
-  float* const twl = kStack ? sring + kSRingRows * kSRingPitch : ring + kRingRows * RP;
+  constexpr bool kMirror = ring_rows(RP) > 32;  // ring rows 0..7 repeated behind row 31
+  float* const twl = kStack ? sring + kSRingRows * kSRingPitch : ring + ring_rows(RP) * RP;
 
   constexpr bool kSpecOut = (OUT == kOutSpec || OUT == kOutLogspec || kStack);
   constexpr bool kLogOut = (OUT == kOutLogspec || OUT == kOutLogspecStack);
@@ -557,12 +561,14 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     if (interior) {
       // two regressions per packed instruction: the rows are read once as the pairs (v0,v1) .. (v6,v7)
       // and once more as (v1,v2) .. (v7,v8); same operations in the same order as regress()
-      const float* const w0 = ring + ((r - kHalo - s_lo + 8) & 31) * RP + q;
+      const int b0 = r - kHalo - s_lo + 8;
+      const float* const w0 = ring + (b0 & 31) * RP + q;
+      auto at = [&](int m) { return kMirror ? w0[m * RP] : ring[((b0 + m) & 31) * RP + q]; };
       cf pe[4], po[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        pe[m] = mk(w0[2 * m * RP], w0[(2 * m + 1) * RP]);
-        po[m] = mk(w0[(2 * m + 1) * RP], w0[(2 * m + 2) * RP]);
+        pe[m] = mk(at(2 * m), at(2 * m + 1));
+        po[m] = mk(at(2 * m + 1), at(2 * m + 2));
       }
       const cf two = mk(2.f, 2.f), zero = mk(0.f, 0.f), tenth = mk(0.1f, 0.1f);
       auto regress2 = [&](cf a, cf b, cf m, cf dd, cf e) {
@@ -1068,7 +1074,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         if (OUT == kOutMfcc39) {
           const int rho = (t - s_lo + 8) & 31;
           ring[rho * RP + q] = v;
-          if (rho < 8) ring[(rho + 32) * RP + q] = v;
+          if (kMirror && rho < 8) ring[(rho + 32) * RP + q] = v;
         } else {
           out_t0[(t - t0) * ld + q] = v;
         }
