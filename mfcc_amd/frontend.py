@@ -60,6 +60,17 @@ def _device(device=None):
     return dev
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
 def _on(dev, *tensors):
     """Context for one launch on ``dev``: every tensor handed to the library must live there,
     and the device is made current so that the stream passed down is that device's current
@@ -67,6 +78,8 @@ def _on(dev, *tensors):
     for t in tensors:
         if t is not None and t.device != dev:
             raise ValueError(f"tensor on {t.device}, but the plan / layout / other operands live on {dev}")
+    if torch.cuda.current_device() == dev.index:
+        return _NO_SWITCH   # already current: entering torch.cuda.device() costs several microseconds per launch
     return torch.cuda.device(dev)
 
 
