@@ -225,6 +225,25 @@ extern "C" void mfcc_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p;
 // launch_fused selectors of the stacked spectrum kinds (not part of the public out_kind values)
 enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101, kLaunchStream = 102 };
 
+// The stacked-spectrum kernels use more dynamic LDS than a kernel may have without asking.  Asked once
+// per device, at plan creation (with that device current), so that a launch is nothing but a launch
+// (it may sit inside a stream capture).
+static int allow_stacked_lds() {
+  const int bytes = (int)(mfcc::smem_floats_stacked() * sizeof(float)) + MFCC_EXTRA_SMEM;
+#define MFCC_ALLOW(OUT, T, G) \
+  HIP_TRY(hipFuncSetAttribute((const void*)mfcc::fused_kernel<OUT, 0, T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
+  MFCC_ALLOW(mfcc::kOutSpecStack, int16_t, mfcc::Geom16k);
+  MFCC_ALLOW(mfcc::kOutSpecStack, float, mfcc::Geom16k);
+  MFCC_ALLOW(mfcc::kOutSpecStack, int16_t, mfcc::Geom8k);
+  MFCC_ALLOW(mfcc::kOutSpecStack, float, mfcc::Geom8k);
+  MFCC_ALLOW(mfcc::kOutLogspecStack, int16_t, mfcc::Geom16k);
+  MFCC_ALLOW(mfcc::kOutLogspecStack, float, mfcc::Geom16k);
+  MFCC_ALLOW(mfcc::kOutLogspecStack, int16_t, mfcc::Geom8k);
+  MFCC_ALLOW(mfcc::kOutLogspecStack, float, mfcc::Geom8k);
+#undef MFCC_ALLOW
+  return MFCC_OK;
+}
+
 // One workgroup per tile; template arguments select the output kind, a compile-time numcep of 13
 // where it pays, and the sample type.
 static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int64_t n_tiles, int32_t out_kind, bool i16,
@@ -248,16 +267,11 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
   const bool stacked = out_kind == kLaunchSpecStack || out_kind == kLaunchLogspecStack;
   const size_t smem = (stacked ? mfcc::smem_floats_stacked() : mfcc::smem_floats(ring_pitch)) * sizeof(float) + MFCC_EXTRA_SMEM;
   const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
-  // the stacked kinds take more than the 64 KiB of dynamic LDS a kernel gets without asking
-#define MFCC_LAUNCH_K(KERNEL)                                                                                              \
-  do {                                                                                                                     \
-    if (smem > 65536) (void)hipFuncSetAttribute((const void*)(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((KERNEL), grid, block, smem, st, fp);                                                               \
-  } while (0)
-#define MFCC_LAUNCH_G(OUT, NCEP, G)                                                 \
-  do {                                                                              \
-    if (i16) MFCC_LAUNCH_K((mfcc::fused_kernel<OUT, NCEP, int16_t, G>));            \
-    else MFCC_LAUNCH_K((mfcc::fused_kernel<OUT, NCEP, float, G>));                  \
+  // (the stacked kinds take more than the 64 KiB of dynamic LDS a kernel gets without asking: allow_stacked_lds())
+#define MFCC_LAUNCH_G(OUT, NCEP, G)                                                                          \
+  do {                                                                                                       \
+    if (i16) hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, int16_t, G>), grid, block, smem, st, fp);     \
+    else hipLaunchKernelGGL((mfcc::fused_kernel<OUT, NCEP, float, G>), grid, block, smem, st, fp);           \
   } while (0)
 #define MFCC_LAUNCH(OUT, NCEP)                                 \
   do {                                                         \
@@ -283,7 +297,6 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
       else MFCC_LAUNCH(mfcc::kOutStream, 0);
       break;
   }
-#undef MFCC_LAUNCH_K
 #undef MFCC_LAUNCH_G
 #undef MFCC_LAUNCH
 }
@@ -648,6 +661,7 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
       if (rc == 1) { specialised = false; rc = MFCC_OK; }
     }
     if (!specialised && !rc) rc = build_general(p);
+    if (specialised && !rc) rc = allow_stacked_lds();
   } catch (const std::bad_alloc&) {
     rc = fail(MFCC_ERR_NOMEM, "mfcc_plan_create: out of host memory");
   }

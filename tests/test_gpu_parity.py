@@ -724,6 +724,16 @@ def test_forward_is_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, fe.forward(audio2, lay))
+    # the one-launch stacked spectrum (more LDS than a kernel gets by default: granted at plan creation) captures too
+    ctx = torch.zeros((lay.total_frames, 17 * 257), dtype=torch.float32, device="cuda")
+    eager = mfcc_amd.spectrum_stack(fe, audio, lay, 17).clone()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        mfcc_amd.spectrum_stack(fe, audio, lay, 17, out=ctx)
+    ctx.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ctx, eager)
 
 
 @pytest.mark.gpu
