@@ -299,3 +299,20 @@ def test_spectrum_stack_other_instantiations(M):
     layb = fe.layout([n_len] * n_utt)
     specb = fe.forward(big, layb, kind="spec")
     assert torch.equal(M.spectrum_stack(fe, big, layb, 17, log=False), M.stack_context(specb, 17, frame_counts=np.diff(layb.frame_offsets)))
+
+
+def test_corpus_pipeline_statistics_per_chunk_or_at_the_end(M):
+    """corpus_mfcc_cmvn: the statistics pass after every chunk or once over the resident rows -- same
+    count, sums equal to float64 rounding, normalised rows equal to float32 rounding of the constants."""
+    rng = np.random.default_rng(77)
+    lengths = [int(v) for v in rng.integers(1500, 9000, size=50)]
+    audio = torch.from_numpy(np.concatenate([np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths])).cuda()
+    fe = M.MFCC("self5")
+    a = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=7)
+    b = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=7, per_chunk_sums=True)
+    c = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=1000, static_scratch=True)
+    for other in (b, c):
+        assert other[1][0] == a[1][0]
+        assert np.allclose(other[1].cpu().numpy(), a[1].cpu().numpy(), rtol=1e-12, atol=1e-7)
+        assert (other[0] - a[0]).abs().max() < 1e-5
+    assert torch.equal(a[0], c[0])    # one pass over the same rows in the same order: same bits, whatever the chunking
