@@ -93,13 +93,15 @@ __host__ __device__ constexpr int row_skew(int r) { return 32 * ((r >> 3) & 1) +
 constexpr int kRowPad = 260;                         // bins 0..256 plus zeros up to a multiple of 4
 constexpr int kXbufFloats = kBatch * kSlot;          // exchange buffers (fb*512) / spectrum rows
 constexpr int kAbufFloats = 2808;                    // staged audio: kStage + up to 7 alignment samples, whole chunks
-// Partial-DCT tile of a wave: element (frame f, coefficient c) at [(c / 4) * 17 + f] * 4 + c % 4, i.e. four
-// blocks (one per 4 coefficients) of 16 frame slots + 1 spare slot of 16 bytes.  A lane's four
-// coefficients are one ds_write_b128 and the 8 lanes of a write group are contiguous; the spare
-// slot of block b carries the wave's energy partials of frames 4b .. 4b+3.
-constexpr int kPartSlots = 17;
-constexpr int kPartTile = 4 * kPartSlots * 4;
-constexpr int kPartFloats = 4 * kPartTile;
+// Partial DCT sums (one share per wave, the filters it owns) of frame slot i live in the upper part
+// of that slot's 2 KiB (the spectrum row ends below float 320, the exchange of the next transform
+// is written by the very wave that reads the shares, later in its program): coefficient c of wave w
+// at float kPartBase + ((16 w + (c & ~3) + 4 i) mod 64) + (c & 3) -- a lane's four coefficients are one
+// 16-byte write, and the eight frames of a write group land on 32 different banks -- and the wave's
+// share of the frame's energy sum at kPartEnergy + w.
+constexpr int kPartBase = 320, kPartEnergy = 384;
+static_assert(56 + kRowPad <= kPartBase, "the shares of a frame slot start behind its spectrum row");
+__host__ __device__ constexpr int part_index(int slot, int w, int c) { return slot * kSlot + kPartBase + ((16 * w + (c & ~3) + 4 * slot) & 63) + (c & 3); }
 // Ring of static-feature rows for the delta / delta-delta regression: row t of the tile sits at
 // ring row (t - s_lo + 8) mod 32; ring rows 0..7 are mirrored at 32..39 so that the 9 rows
 // t-4 .. t+4 a lane reads are always consecutive.
@@ -113,7 +115,7 @@ constexpr int kTwPitch = 52;
 constexpr int kTwUnt = 0, kTwSt1 = 8;                // complex index of the first untangle / stage-1 value
 constexpr int kTwFloats = 16 * kTwPitch;
 // ring_pitch = floats per ring row: numcep where it is a compile-time constant, else kMaxCep
-constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + kPartFloats + ring_rows(ring_pitch) * ring_pitch + kTwFloats; }
+constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + ring_rows(ring_pitch) * ring_pitch + kTwFloats; }
 // Stacked spectrum kinds: instead of the partial-DCT tiles and the statics ring, a ring of the last
 // 32 spectrum rows (frame s of the tile at ring row (s - s_lo) mod 32, 257 values behind a phase of
 // 0..3 floats), from which whole output rows are written.  81 632 bytes: two workgroups per CU
@@ -442,8 +444,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   // of LDS they never touch, one allocation unit too many for three workgroups per CU)
   constexpr int RP = OUT == kOutMfcc39 ? (NCEP > 0 ? NCEP : kMaxCep) : 0;
   constexpr bool kStack = (OUT == kOutSpecStack || OUT == kOutLogspecStack);
-  float* const part = abuf + kAbufFloats;
-  float* const ring = part + kPartFloats;
+  float* const ring = abuf + kAbufFloats;
   float* const sring = abuf + kAbufFloats;  // stacked kinds: ring of spectrum rows in place of part / ring
   constexpr bool kMirror = ring_rows(RP) > 32;  // ring rows 0..7 repeated behind row 31
   float* const twl = kStack ? sring + kSRingRows * kSRingPitch : ring + ring_rows(RP) * RP;
@@ -1017,8 +1018,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // ln for the ln-mel output; the chained DCT takes log2 (its weights carry the factor ln 2)
 #pragma unroll
       for (int r = 0; r < 4; ++r) lm[r] = g4 + 4 * r < mel_nf ? (OUT == kOutLogmel ? fast_ln(mv[r]) : __builtin_amdgcn_logf(mv[r])) : 0.f;
-      float* const tile_w = part + wave * kPartTile;
-      if (g4 == 3) tile_w[((q >> 2) * kPartSlots + 16) * 4 + (q & 3)] = acc[3];
+      if (g4 == 3) xbuf[q * kSlot + kPartEnergy + wave] = acc[3];
       if (OUT == kOutLogmel) {
         const int t = tb + q;
         if (t < s_hi) {
@@ -1035,7 +1035,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #pragma unroll
         for (int r = 1; r < 4; ++r)
           if (4 * r < mel_nf) pd = __builtin_amdgcn_mfma_f32_16x16x4f32(dw[r], lm[r], pd, 0, 0, 0);
-        *(f32x4*)__builtin_assume_aligned(tile_w + (g4 * kPartSlots + q) * 4, 16) = pd;
+        *(f32x4*)__builtin_assume_aligned(xbuf + part_index(q, wave, 4 * g4), 16) = pd;
       }
     }
     // rows of the batch before last whose +-4-row context is now complete leave as whole output rows
@@ -1051,14 +1051,15 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 
     // energy partials of frame slot i: spare slot of coefficient block i / 4 in every wave's tile
     auto energy_of = [&](int i) {
-      const float* const ee = part + ((i >> 2) * kPartSlots + 16) * 4 + (i & 3);
-      float e = (ee[0] + ee[kPartTile]) + (ee[2 * kPartTile] + ee[3 * kPartTile]);
+      const float* const ee = xbuf + i * kSlot + kPartEnergy;
+      float e = (ee[0] + ee[1]) + (ee[2] + ee[3]);
       if (e == 0.f) e = kEps64;  // mfcc-self5.py:130-132
       return fast_ln(e);
     };
     if (OUT == kOutLogmel) {
       // the ln-mel columns went out from registers; the energy column needs the four partials
-      if (tid < kBatch && tb + tid < s_hi) out_t0[(tb - t0 + tid) * ld + nmel] = energy_of(tid);
+      // (every wave for its own four frames: their slots are the ones it overwrites next)
+      if (q == 0 && tb + 4 * wave + g4 < s_hi) out_t0[(tb - t0 + 4 * wave + g4) * ld + nmel] = energy_of(4 * wave + g4);
       continue;  // the tiles are rewritten only after the next spectrum barrier
     }
     {
@@ -1066,8 +1067,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // mfcc-self5.py:130-132 and :164); wave w finishes frames 4 w .. 4 w + 3, lane = (frame, coefficient)
       const int i = 4 * wave + g4;
       const int t = tb + i;
-      const float* const pp = part + ((q >> 2) * kPartSlots + i) * 4 + (q & 3);
-      float v = (pp[0] + pp[kPartTile]) + (pp[2 * kPartTile] + pp[3 * kPartTile]);
+      float v = (xbuf[part_index(i, 0, q)] + xbuf[part_index(i, 1, q)]) + (xbuf[part_index(i, 2, q)] + xbuf[part_index(i, 3, q)]);
       const float e = energy_of(i);
       if (q == 0) v = e;
       if (q < ncep && t < s_hi) {
