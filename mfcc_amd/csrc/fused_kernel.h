@@ -224,20 +224,31 @@ __device__ __forceinline__ void stream_carry(const StreamStep& s, int b, T* seg,
   }
 }
 
+// The regression of mfcc-self5.py:169-179 for pad_fac = 2: (-2a - b + 0m + d + 2e) / 10.  The zero-weight
+// centre tap keeps NaN propagation identical to np.dot over the window.  Written with explicit
+// roundings so that every caller (the fused kernel's scalar and packed forms, the streaming rows)
+// gets the same bits: left to the compiler, the final product may or may not be fused into the
+// caller's next subtraction.
+__device__ __forceinline__ float regress5(float a, float b, float m, float d, float e) {
+#pragma clang fp contract(off)  // the operations below carry no licence to be fused with a caller's, wherever this is inlined
+  const float ea = e - a, db = d - b;
+  const float t = fmaf(0.f, m, fmaf(2.f, ea, db));
+  return t * 0.1f;
+}
+
 // One output row element: [c | delta | delta-delta] of frame e for coefficient c, the regression of
 // mfcc-self5.py:169-179 applied twice.  S = the stream's static rows, row 0 = first new frame of
 // this step, column c; taps are clamped to [lo, hi]: lo = the utterance's frame 0, hi = its last
 // frame at flush (edge replication, mfcc-self5.py:174) or out of reach before.
 __device__ __forceinline__ void stream_emit_one(const float* S, int e, int lo, int hi, int ncep, int c, float* o) {
   auto st = [&](int u) { return S[min(max(u, lo), hi) * kMaxCep]; };
-  auto reg = [](float a, float bb, float m, float d, float ee) { return (2.f * (ee - a) + (d - bb) + 0.f * m) * 0.1f; };
   auto dl = [&](int v) {
     v = min(max(v, lo), hi);
-    return reg(st(v - 2), st(v - 1), st(v), st(v + 1), st(v + 2));
+    return regress5(st(v - 2), st(v - 1), st(v), st(v + 1), st(v + 2));
   };
   o[c] = st(e);
   o[ncep + c] = dl(e);
-  o[2 * ncep + c] = reg(dl(e - 2), dl(e - 1), dl(e), dl(e + 1), dl(e + 2));
+  o[2 * ncep + c] = regress5(dl(e - 2), dl(e - 1), dl(e), dl(e + 1), dl(e + 2));
 }
 
 struct FusedParams {
@@ -545,7 +556,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   // ---- delta, delta-delta and the output rows (mfcc-self5.py:169-186) ------------------------
   // (-2a - b + 0m + d + 2e) / 10; the zero-weight centre tap keeps NaN propagation identical to
   // np.dot over the window
-  auto regress = [](float a, float b, float m, float d, float e) { return (2.f * (e - a) + (d - b) + 0.f * m) * 0.1f; };
+  auto regress = [](float a, float b, float m, float d, float e) { return regress5(a, b, m, d, e); };
   // Rows r_first .. r_first + 15 (those inside the tile): wave w, lane group g4 take row
   // r_first + 4 w + g4, lane q its coefficient q, and write c | delta | delta-delta of that row, so
   // the three stores of a wave cover four whole consecutive output rows.  The statics of rows

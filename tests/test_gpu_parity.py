@@ -438,6 +438,24 @@ def test_streaming_short_utterances(L):
 
 
 @pytest.mark.gpu
+def test_streaming_equals_offline_bit_for_bit():
+    """Streamed rows equal the offline rows of the same plan bit for bit (both form delta and
+    delta-delta with the same explicitly rounded regression), also with a numcep other than 13 (the
+    kernels with a run-time coefficient count)."""
+    import mfcc_amd
+    rng = np.random.default_rng(12)
+    audio = np.clip(rng.standard_normal((3, 7000)) * 3000, -32768, 32767).astype(np.int16)
+    dev = torch.from_numpy(audio).cuda()
+    for numcep, nb in ((13, 26), (12, 33), (16, 33)):
+        s = mfcc_amd.StreamingMFCC("self5", n_streams=3, max_chunk=480, numcep=numcep, num_bins=nb)
+        got = _stream_all(s, dev, [160, 480, 33])
+        fe = mfcc_amd.MFCC("self5", numcep=numcep, num_bins=nb)
+        off = fe(dev)
+        assert got.shape == (3, off.shape[0] // 3, 3 * numcep)
+        assert torch.equal(got.reshape(-1, 3 * numcep), off)
+
+
+@pytest.mark.gpu
 def test_streaming_float_input_numpy_and_errors():
     import mfcc_amd
     from oracle import mfcc_oracle as O
