@@ -84,6 +84,21 @@ def cpu_model():
     return "unknown"
 
 
+def free_port():
+    """A TCP port nobody listens on right now, for the rendezvous of a hand-started N-rank run."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def max_over_ranks(value, dist, torch, dev):
+    """MAX of a host float over the ranks (device tensor for RCCL, host tensor for gloo)."""
+    t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def kernel_revision():
     """Identifies the kernel sources a measurement belongs to: sha1 over mfcc_amd/csrc/*."""
     import glob
@@ -101,6 +116,45 @@ def synth_audio(n_utt, dev, gen, torch):
         m = min(1000, n_utt - i)
         audio[i:i + m] = (torch.randn(m, UTT_LEN, generator=gen, device=dev) * 3000).clamp(-32768, 32767).to(torch.int16)
     return audio
+
+
+def precondition(step, torch, cap=100, window=10):
+    """Untimed clock-ramp phase, separate from (and in front of) the --warmup launches: a cold part
+    raises its clocks over the first few dozen launches of this kernel, and a short run would time the
+    ramp instead of the kernel.  Launches run in windows of `window`; the phase ends when the median
+    launch time of a window is within 1 % of the window before it, or after `cap` launches."""
+    medians, first, last, n = [], None, None, 0
+    while n < cap:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(window)]
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        torch.cuda.synchronize()
+        w = [a.elapsed_time(b) for a, b in evs]
+        n += window
+        first = w[0] if first is None else first
+        last = w[-1]
+        medians.append(sorted(w)[len(w) // 2])
+        if len(medians) >= 2 and abs(medians[-1] - medians[-2]) <= 0.01 * medians[-2]:
+            break
+    return {"preconditioning_launches": n, "first_launch_ms": round(first, 4), "last_launch_ms": round(last, 4),
+            "window_median_ms": [round(m, 4) for m in medians],
+            "note": "untimed clock-ramp launches in front of the --warmup launches; not part of steps, warmup or value"}
+
+
+def check_config_c(torch, mfcc_amd, fe, audio, ctx, n_check=16):
+    """Rows of the one-launch stacked output against the two-kernel route (spectrum rows of the same
+    utterances, then stack_context) on n_check utterances spread over the batch, first and last included."""
+    import numpy as np
+    picks = sorted(set(np.linspace(0, N_UTT - 1, n_check).astype(int).tolist()))
+    sub = audio[picks].contiguous().view(-1)
+    lay = fe.layout([UTT_LEN] * len(picks))
+    spec = fe.forward(sub, lay, kind="logspec")
+    want = mfcc_amd.stack_context(spec, 17, frame_counts=[FRAMES_PER_UTT] * len(picks))
+    got = torch.cat([ctx[u * FRAMES_PER_UTT:(u + 1) * FRAMES_PER_UTT] for u in picks])
+    same = bool(torch.equal(got, want)) and bool(torch.isfinite(got).all())
+    return same, f"{len(picks)} utterances x {FRAMES_PER_UTT} rows x 4369 floats bit-equal to forward(logspec) + stack_context"
 
 
 def extra_measurements(torch, mfcc_amd, dev, audio, fe, layout):
@@ -127,9 +181,10 @@ def extra_measurements(torch, mfcc_amd, dev, audio, fe, layout):
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in ev)[2]
         alg = 2 * N_UTT * UTT_LEN + 4 * 257 * 17 * frames
+        checked, how = check_config_c(torch, mfcc_amd, fe, audio, ctx)
         extra["C"] = {"workload": "10000 x 3 s -> ln |X|^2/512 [frames, 257] -> 17-frame stack [frames, 4369] (BASELINE.json configs[2])",
                       "ms": round(ms, 3), "frames_per_s": round(frames / (ms * 1e-3), 1), "algorithmic_bytes": alg,
-                      "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                      "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "checked": checked, "check": how}
         del ctx
         torch.cuda.empty_cache()
     except Exception as exc:   # a secondary figure must not take the headline down
@@ -155,6 +210,46 @@ def extra_measurements(torch, mfcc_amd, dev, audio, fe, layout):
     except Exception as exc:
         extra["E"] = {"error": repr(exc)[:200]}
     return extra
+
+
+def check_config_d(torch, feats, audio, n_local, mm, vv, variant, world, n_check=8):
+    """Checks of the corpus pipeline's result, outside the clock.  (1) Sampled utterances of this rank
+    against the CPU oracle (the checker, never the product): normalised rows vs (oracle rows + mm) * vv,
+    bound 1e-3 * vv per column as for the un-normalised rows.  (2) Every row of this rank's shard:
+    float64 column moments of the normalised rows (exactly 0 and 1 on one rank; with more ranks the
+    shard's own moments only approximate the corpus constants)."""
+    import numpy as np
+    from oracle import mfcc_oracle as O
+    picks = sorted(set(np.linspace(0, n_local - 1, n_check).astype(int).tolist()))
+    mm64, vv64 = mm.double().cpu().numpy(), vv.double().cpu().numpy()
+    worst = 0.0
+    ok = True
+    for u in picks:
+        a = audio[u * UTT_LEN:(u + 1) * UTT_LEN].cpu().numpy()
+        want = (O.mfcc39(a, variant, loop=False) + mm64) * vv64
+        got = feats[u * FRAMES_PER_UTT:(u + 1) * FRAMES_PER_UTT].double().cpu().numpy()
+        err = np.abs(got - want) / vv64
+        worst = max(worst, float(err.max()))
+        ok = ok and bool((err <= 1e-3 + 1e-6 * np.abs(want / vv64)).all())
+    s1 = torch.zeros(feats.shape[1], dtype=torch.float64, device=feats.device)
+    s2 = torch.zeros_like(s1)
+    for i in range(0, feats.shape[0], 1 << 22):
+        x = feats[i:i + (1 << 22)].double()
+        s1 += x.sum(0)
+        s2 += (x * x).sum(0)
+    n = feats.shape[0]
+    mean = s1 / n
+    var = s2 / n - mean * mean
+    res = {"oracle_checked": ok, "oracle_sample": f"{len(picks)} utterances ({len(picks) * FRAMES_PER_UTT} rows) of rank 0",
+           "oracle_max_abs_err_unnormalised_units": round(worst, 7),
+           "normalised_mean_abs_max_all_rows_rank0": float(mean.abs().max().item()),
+           "normalised_var_minus_1_abs_max_all_rows_rank0": float((var - 1).abs().max().item())}
+    if world == 1:
+        ok_m = res["normalised_mean_abs_max_all_rows_rank0"] < 1e-4 and res["normalised_var_minus_1_abs_max_all_rows_rank0"] < 1e-3
+        res["moments_checked"] = bool(ok_m)
+        assert ok_m, res
+    assert ok, res
+    return res
 
 
 def run_config_d(args, rank, world, dev, torch, mfcc_amd, dist):
@@ -194,11 +289,9 @@ def run_config_d(args, rank, world, dev, torch, mfcc_amd, dist):
         for k, evs in events.items():
             phase_ms[k] = phase_ms.get(k, 0.0) + sum(a.elapsed_time(b) for a, b in evs)
     n_in_sums = int(sums[0].item())
-    mean_abs = float(feats[:: 997].double().mean(0).abs().max().item())
+    checks = check_config_d(torch, feats, audio, n_local, mm, vv, args.variant, world) if rank == 0 else None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, dist, torch, dev)
     assert n_in_sums == n_total * FRAMES_PER_UTT, (n_in_sums, n_total * FRAMES_PER_UTT)
     if rank == 0:
         total_frames = n_total * FRAMES_PER_UTT
@@ -219,7 +312,7 @@ def run_config_d(args, rank, world, dev, torch, mfcc_amd, dist):
                          "frac": round(alg_rank / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_step_rank0": alg_rank,
                          "note": "two passes over the features: 2 B/sample + 156 B/frame written, then 156 B/frame read and written"},
-            "checks": {"frames_in_sums": n_in_sums, "normalised_mean_abs_max_sampled": mean_abs},
+            "checks": dict(checks, frames_in_sums=n_in_sums),
         }
         print(json.dumps(rec), flush=True)
 
@@ -235,6 +328,9 @@ def main():
     ap.add_argument("--hours", type=float, default=None, help="config D: corpus size in hours (default 125 per GPU: 1000 h on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the compact config C / E figures")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend for N > 1: nccl = RCCL over xGMI (default); gloo lets N ranks share one GPU (tests)")
+    ap.add_argument("--no-precondition", action="store_true", help="skip the untimed clock-ramp launches in front of the warm-up")
     args = ap.parse_args()
     # Defaults of config B: the part ramps its clocks up over the first ~35 launches of a cold start
     # (per-launch times in profiles/r2_final_kernel_trace_durations.txt), so 60 untimed launches come first.
@@ -246,7 +342,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         # started by hand without a launcher: start one process per GPU and relay the result
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
@@ -260,12 +356,17 @@ def main():
     import torch
     import mfcc_amd
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank; under gloo several ranks may share a GPU (a one-GPU box rehearsing the N-rank path)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     if args.config == "D":
         if args.hours is None:
@@ -287,6 +388,7 @@ def main():
     def step():
         fe.forward(flat, layout, out=out, kind="mfcc39")
 
+    pre = None if args.no_precondition else precondition(step, torch)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -308,9 +410,7 @@ def main():
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, dist, torch, dev)
         # the one exchange of the front-end, outside the timed region: corpus CMVN sums
         sums = mfcc_amd.cmvn_allreduce(mfcc_amd.cmvn_accumulate(out))
         assert int(sums[0].item()) == frames * world
@@ -380,6 +480,8 @@ def main():
                 "note": "minimum-work count (split-radix real FFT, sparse filterbank); secondary line, the HBM roofline is the headline",
             },
         }
+        if pre is not None:
+            rec["preconditioning"] = pre
         if cpu is not None:
             rec["cpu_baseline"] = cpu
         if extra is not None:

@@ -16,7 +16,7 @@
  *   - a plan / layout belongs to the device it was created on; the caller
  *     keeps that device current while using it;
  *   - no call allocates device memory except the *_create functions and the first
- *     mfcc_cmvn_accumulate on a (device, stream) pair.
+ *     mfcc_cmvn_accumulate on a (device, stream) pair (16 MiB, kept until mfcc_cmvn_release).
  */
 #ifndef MFCC_AMD_H
 #define MFCC_AMD_H
@@ -121,6 +121,12 @@ int mfcc_plan_info(const mfcc_plan* plan, int32_t* frame_size, int32_t* frame_st
                    int32_t* num_bins, int32_t* numcep);
 /* MFCC_KERNEL_GENERAL if the plan runs the general kernel, MFCC_KERNEL_AUTO (0) if the specialised one */
 int32_t mfcc_plan_kernel(const mfcc_plan* plan);
+/* 1 if mfcc_forward serves out_kind on this plan, 0 if not.  Every plan serves every kind with one
+ * exception: a general-kernel plan whose FFT buffers and filter rows leave no room in a workgroup's
+ * 64 KiB of LDS for the static and delta rows of a tile (2 * numcep floats for each of 4 + 4 * pad_fac
+ * rows; e.g. num_fft 2048 with 128 filters and 64 cepstra) has no fused MFCC_OUT_MFCC39: take
+ * MFCC_OUT_STATIC and apply mfcc_delta (delta, mfcc-self5.py:169-179) per utterance. */
+int32_t mfcc_plan_supports(const mfcc_plan* plan, int32_t out_kind);
 
 /* ---- batch layout ---------------------------------------------------------- */
 /* n_utts utterances stored back to back: utterance u occupies samples
@@ -143,7 +149,9 @@ int mfcc_layout_offsets_host(const mfcc_layout* layout, int64_t* sample_offsets_
  * audio -> pre-emphasis -> framing -> rFFT -> spectrum -> mel -> ln -> DCT -> lifter
  *       -> c0:=lnE -> delta -> delta-delta -> out rows.
  * Replaces main()'s call chain mfcc-self5.py:211-229 (mfcc-self15.py:228-246).
- * `out` has `out_ld` floats per row (>= the row width of out_kind). */
+ * `out` has `out_ld` floats per row (>= the row width of out_kind; plans of the specialised
+ * kernel take out_ld up to 6 391 320 floats, MFCC_ERR_UNSUPPORTED beyond: its row offsets inside
+ * a tile are 32-bit). */
 int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype,
                  float* out, int64_t out_ld, int32_t out_kind, void* stream);
 int32_t mfcc_out_width(const mfcc_plan* plan, int32_t out_kind);
@@ -205,16 +213,25 @@ int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t fe
  * corpus constants (x+mm).*vv of anal_recog_nn_liste.m:180.  The caller zeroes `sums`
  * and combines it across ranks.  The reduction order is fixed by the code (per-workgroup
  * partial sums, then a fixed-order second stage; no atomics), so equal inputs give equal bits.
- * The partial sums live in a buffer the library allocates on first use per (device, stream)
- * and keeps; ncol <= 1024. */
+ * The partial sums live in a 16 MiB buffer that the library allocates at the first call on a
+ * (device, stream) pair -- sized for the widest rows, so no later call allocates, frees or waits --
+ * and keeps until mfcc_cmvn_release; ncol <= 1024.  That first call may not sit inside a stream
+ * capture (it allocates): callers that capture, or that create and destroy streams freely, use
+ * mfcc_cmvn_accumulate_static below. */
 int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums,
                          void* stream);
+/* Frees every buffer mfcc_cmvn_accumulate holds on the current device.  The caller makes sure that
+ * no such call is still running there (e.g. after hipDeviceSynchronize). */
+int mfcc_cmvn_release(void);
 /* No counterpart in the reference.  The same operation with the same results for callers that
  * cannot allocate device memory at call time (code under HIP graph capture, serving loops,
  * harnesses that forbid hipMalloc): the partial sums go to a fixed 4.3 MB device array that is
  * part of the library image (one copy per GPU, held until the process ends), so the call never
  * allocates.  ncol <= MFCC_CMVN_STATIC_MAX_COLS, otherwise MFCC_ERR_UNSUPPORTED.  All calls on one
- * GPU share that array: calls that overlap in time on one GPU (different streams) race. */
+ * GPU share that array.  Eager calls take turns on it whatever their streams: each waits (on its
+ * stream, not on the host) for an event the call before it on that GPU recorded.  A call under
+ * stream capture issues neither the wait nor the record: launches of a graph that contains it, and
+ * eager calls beside them, race on the array unless the caller orders them. */
 #define MFCC_CMVN_STATIC_MAX_COLS 264
 int mfcc_cmvn_accumulate_static(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums,
                                 void* stream);

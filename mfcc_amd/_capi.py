@@ -69,6 +69,7 @@ SIGNATURES = {
     "mfcc_plan_destroy": (C.c_int, [_vp]),
     "mfcc_plan_info": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "mfcc_plan_kernel": (_i32, [_vp]),
+    "mfcc_plan_supports": (_i32, [_vp, _i32]),
     "mfcc_layout_create": (C.c_int, [_vp, _i64p, _i64, C.POINTER(_vp)]),
     "mfcc_layout_create_frames": (C.c_int, [C.c_int, _i64p, _i64, C.POINTER(_vp)]),
     "mfcc_layout_destroy": (C.c_int, [_vp]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "mfcc_stack_context": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mfcc_cmvn_accumulate": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "mfcc_cmvn_accumulate_static": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    "mfcc_cmvn_release": (C.c_int, []),
     "mfcc_cmvn_apply": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "mfcc_utt_scalar_norm": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "mfcc_pad_batch": (C.c_int, [_vp, _vp, _i64, _i32, _i32, C.c_float, _i32, _i32, _vp, _vp]),

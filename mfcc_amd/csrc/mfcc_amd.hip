@@ -48,39 +48,32 @@ int upload(const std::vector<T>& host, T** dev) {
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-// Partial sums of mfcc_cmvn_accumulate: one buffer per (device, stream) that has called it, grown
-// on demand and kept until the process ends.  Calls on one stream are ordered by the stream, calls
-// on different streams get different buffers.
+// Partial sums of mfcc_cmvn_accumulate: one buffer per (device, stream) that has called it, sized
+// at its first call for the widest rows the entry point takes (so it is never grown, freed or
+// waited for afterwards) and kept until mfcc_cmvn_release or the end of the process.  Calls on one
+// stream are ordered by the stream, calls on different streams get different buffers.
+constexpr int kCmvnMaxCols = 1024;
+constexpr size_t kCmvnWorkspaceBytes = (size_t)mfcc::kCmvnMaxBlocks * 2 * kCmvnMaxCols * sizeof(double);  // 16 MiB
 struct CmvnWorkspace {
   int device;
   hipStream_t stream;
   double* ptr;
-  size_t bytes;
 };
 std::mutex g_ws_mutex;
 std::vector<CmvnWorkspace> g_ws;
 
-int cmvn_workspace(hipStream_t stream, size_t bytes, double** out) {
+int cmvn_workspace(hipStream_t stream, double** out) {
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   for (CmvnWorkspace& w : g_ws)
     if (w.device == device && w.stream == stream) {
-      if (w.bytes < bytes) {
-        // the old buffer may still be read by work enqueued earlier on this stream
-        HIP_TRY(hipStreamSynchronize(stream));
-        (void)hipFree(w.ptr);
-        w.ptr = nullptr;
-        w.bytes = 0;
-        HIP_TRY(hipMalloc((void**)&w.ptr, bytes));
-        w.bytes = bytes;
-      }
       *out = w.ptr;
       return MFCC_OK;
     }
   double* p = nullptr;
-  HIP_TRY(hipMalloc((void**)&p, bytes));
-  g_ws.push_back(CmvnWorkspace{device, stream, p, bytes});
+  HIP_TRY(hipMalloc((void**)&p, kCmvnWorkspaceBytes));
+  g_ws.push_back(CmvnWorkspace{device, stream, p});
   *out = p;
   return MFCC_OK;
 }
@@ -93,11 +86,14 @@ constexpr size_t kCmvnStaticDoubles = (size_t)mfcc::kCmvnMaxBlocks * 2 * kCmvnSt
 static __device__ __align__(256) double g_cmvn_scratch[kCmvnStaticDoubles];  // 4.3 MB
 constexpr int kMaxDevices = 64;
 double* g_cmvn_scratch_ptr[kMaxDevices] = {};
+// Recorded behind every (non-captured) call of the static entry point on the device and waited for by
+// the next one, so that calls from different streams take turns on the one array instead of racing.
+hipEvent_t g_cmvn_scratch_event[kMaxDevices] = {};
 std::mutex g_scratch_mutex;
 
 // Device address of g_cmvn_scratch on the current device (resolved once per device: the array's
 // name is only a host-side handle, each GPU holds its own copy at its own address).
-int cmvn_static_scratch(double** out) {
+int cmvn_static_scratch(double** out, hipEvent_t* event = nullptr) {
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
   if (device < 0 || device >= kMaxDevices) return fail(MFCC_ERR_UNSUPPORTED, "device index %d outside 0..%d", device, kMaxDevices - 1);
@@ -106,9 +102,11 @@ int cmvn_static_scratch(double** out) {
     void* p = nullptr;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_cmvn_scratch)));
     if (!p) return fail(MFCC_ERR_HIP, "hipGetSymbolAddress returned a null address for the CMVN scratch");
+    HIP_TRY(hipEventCreateWithFlags(&g_cmvn_scratch_event[device], hipEventDisableTiming));
     g_cmvn_scratch_ptr[device] = (double*)p;
   }
   *out = g_cmvn_scratch_ptr[device];
+  if (event) *event = g_cmvn_scratch_event[device];
   return MFCC_OK;
 }
 
@@ -169,6 +167,7 @@ struct mfcc_plan {
   // general kernel (general_kernel.h): set when the configuration is outside the specialised kernel
   bool general = false;
   int32_t gen_nt_max = 0;  // output frames per tile
+  bool gen_no_delta = false;  // no room in LDS for a tile's static / delta rows: every kind but MFCC-39
   size_t gen_smem = 0;     // dynamic LDS per workgroup
   mfcc::GeneralConst gc_host;
   mfcc::GeneralConst* gc = nullptr;
@@ -544,10 +543,17 @@ static int build_general(mfcc_plan* p) {
     table_floats = bank_pad + dct_pad;
   }
   const int64_t rows_fit = ((int64_t)65536 - (int64_t)fixed_bytes - (int64_t)(table_floats * sizeof(float))) / (int64_t)row_bytes;
-  const int rows = (int)std::min<int64_t>(rows_fit, mfcc::kGenMaxTile + 4 * pf);
-  if (rows - 4 * pf < 4)
-    return fail(MFCC_ERR_UNSUPPORTED, "num_fft=%d, num_bins=%d, numcep=%d, pad_fac=%d need more LDS than a workgroup has", nfft, nmel, ncep, pf);
-  p->gen_nt_max = rows - 4 * pf;
+  int rows = (int)std::min<int64_t>(rows_fit, mfcc::kGenMaxTile + 4 * pf);
+  if (rows - 4 * pf < 4) {
+    // Too little LDS left for the static and delta rows of even a four-frame tile (e.g. 2048-point FFT,
+    // 128 filters, 64 cepstra): only the MFCC-39 kind uses those rows, so the plan serves every other
+    // kind and mfcc_forward refuses that one.
+    if ((int64_t)fixed_bytes + (int64_t)(table_floats * sizeof(float)) > 65536)
+      return fail(MFCC_ERR_UNSUPPORTED, "num_fft=%d, num_bins=%d need more LDS than a workgroup has", nfft, nmel);
+    p->gen_no_delta = true;
+    rows = 0;
+  }
+  p->gen_nt_max = p->gen_no_delta ? mfcc::kGenMaxTile : rows - 4 * pf;
   p->gen_smem = mfcc::general_smem_bytes(nfft, nmel, ncep, rows) + table_floats * sizeof(float);
 
   const std::vector<double> dl = mfcc::dct_lifter(nmel, ncep, cfg->lift_factor, true);
@@ -704,6 +710,12 @@ int mfcc_plan_info(const mfcc_plan* p, int32_t* frame_size, int32_t* frame_step,
 int32_t mfcc_plan_kernel(const mfcc_plan* p) {
   if (!p) return fail(MFCC_ERR_INVALID, "mfcc_plan_kernel: null plan");
   return p->general ? MFCC_KERNEL_GENERAL : MFCC_KERNEL_AUTO;
+}
+
+int32_t mfcc_plan_supports(const mfcc_plan* p, int32_t out_kind) {
+  if (!p) return fail(MFCC_ERR_INVALID, "mfcc_plan_supports: null plan");
+  if (out_kind < MFCC_OUT_MFCC39 || out_kind > MFCC_OUT_LOGSPEC) return fail(MFCC_ERR_INVALID, "out_kind=%d", out_kind);
+  return (p->general && p->gen_no_delta && out_kind == MFCC_OUT_MFCC39) ? 0 : 1;
 }
 
 int32_t mfcc_out_width(const mfcc_plan* p, int32_t out_kind) {
@@ -894,6 +906,13 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   const int32_t width = mfcc_out_width(plan, out_kind);
   if (width < 0) return width;
   if (out_ld < width) return fail(MFCC_ERR_INVALID, "out_ld=%lld < row width %d", (long long)out_ld, width);
+  // the specialised kernel addresses the rows of a tile (up to 19 batches + halo) with 32-bit offsets from the tile's first row
+  if (!plan->general && out_ld * (int64_t)(mfcc::tile_frames_for(plan->cfg.numcep) + 2 * mfcc::kBatch) >= ((int64_t)1 << 31))
+    return fail(MFCC_ERR_UNSUPPORTED, "out_ld=%lld: rows more than %lld floats apart are beyond the specialised kernel's 32-bit row offsets",
+                (long long)out_ld, (long long)((((int64_t)1 << 31) - 1) / (mfcc::tile_frames_for(plan->cfg.numcep) + 2 * mfcc::kBatch)));
+  if (plan->general && plan->gen_no_delta && out_kind == MFCC_OUT_MFCC39)
+    return fail(MFCC_ERR_UNSUPPORTED, "num_fft=%d, num_bins=%d, numcep=%d, pad_fac=%d: the delta rows of a tile do not fit a workgroup's LDS; "
+                "take MFCC_OUT_STATIC and apply mfcc_delta per utterance", plan->nfft, plan->cfg.num_bins, plan->cfg.numcep, plan->cfg.pad_fac);
   if (layout->n_utts == 0 || layout->n_tiles == 0) return MFCC_OK;
   if (!out || (!audio && layout->total_samples > 0)) return fail(MFCC_ERR_INVALID, "mfcc_forward: null device pointer");
 
@@ -1097,16 +1116,30 @@ int mfcc_stack_context(const mfcc_layout* layout, const float* feats, int64_t fe
 }
 
 int mfcc_cmvn_accumulate(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums, void* stream) {
-  if (n_rows < 0 || ncol < 1 || ncol > 1024 || feats_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate: bad shape");
+  if (n_rows < 0 || ncol < 1 || ncol > kCmvnMaxCols || feats_ld < ncol) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate: bad shape");
   if (n_rows == 0) return MFCC_OK;
   if (!feats || !sums) return fail(MFCC_ERR_INVALID, "mfcc_cmvn_accumulate: null pointer");
   int nblk;
   int64_t rpb;
   cmvn_split(n_rows, &nblk, &rpb);
   double* partial = nullptr;
-  const int rc = cmvn_workspace((hipStream_t)stream, (size_t)mfcc::kCmvnMaxBlocks * 2 * ncol * sizeof(double), &partial);
+  const int rc = cmvn_workspace((hipStream_t)stream, &partial);
   if (rc) return rc;
   return launch_cmvn(feats, feats_ld, n_rows, ncol, sums, partial, nblk, rpb, (hipStream_t)stream);
+}
+
+int mfcc_cmvn_release(void) {
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  for (size_t i = 0; i < g_ws.size();)
+    if (g_ws[i].device == device) {
+      (void)hipFree(g_ws[i].ptr);
+      g_ws.erase(g_ws.begin() + (ptrdiff_t)i);
+    } else {
+      ++i;
+    }
+  return MFCC_OK;
 }
 
 int mfcc_cmvn_accumulate_static(const float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, double* sums, void* stream) {
@@ -1120,11 +1153,24 @@ int mfcc_cmvn_accumulate_static(const float* feats, int64_t feats_ld, int64_t n_
   int64_t rpb;
   cmvn_split(n_rows, &nblk, &rpb);
   double* partial = nullptr;
-  const int rc = cmvn_static_scratch(&partial);
+  hipEvent_t turn = nullptr;
+  const int rc = cmvn_static_scratch(&partial, &turn);
   if (rc) return rc;
+  // Calls from different streams share the one array: outside stream capture each call waits for
+  // the call before it on this device and leaves its own mark (two stream operations, no
+  // allocation, no host wait).  Under capture neither is issued -- an event recorded into a graph
+  // cannot order eager work -- and the captured call is ordered by its graph alone.
+  const hipStream_t st = (hipStream_t)stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  HIP_TRY(hipStreamIsCapturing(st, &cap));
+  const bool eager = cap == hipStreamCaptureStatusNone;
+  if (eager) HIP_TRY(hipStreamWaitEvent(st, turn, 0));
   // every partial the second stage reads is written by the first stage of this very call, so
   // nothing of an earlier call's contents has to be cleared
-  return launch_cmvn(feats, feats_ld, n_rows, ncol, sums, partial, nblk, rpb, (hipStream_t)stream);
+  const int rc_l = launch_cmvn(feats, feats_ld, n_rows, ncol, sums, partial, nblk, rpb, st);
+  if (rc_l) return rc_l;
+  if (eager) HIP_TRY(hipEventRecord(turn, st));
+  return MFCC_OK;
 }
 
 int mfcc_cmvn_apply(float* feats, int64_t feats_ld, int64_t n_rows, int32_t ncol, const float* mm, const float* vv, void* stream) {

@@ -290,6 +290,8 @@ class MFCC:
         if audio.numel() != layout.total_samples:
             raise ValueError(f"audio has {audio.numel()} samples, layout expects {layout.total_samples}")
         width = self.plan.out_width(kind)
+        if kind == "mfcc39" and not capi.check(capi.load().mfcc_plan_supports(self.plan._h, _OUT_KINDS[kind])):
+            return self._mfcc39_by_stages(audio, layout, out)
         if out is None:
             out = torch.empty((layout.total_frames, width), dtype=torch.float32, device=audio.device)
         else:
@@ -302,6 +304,27 @@ class MFCC:
         with _on(self.plan.device, audio, out):
             capi.check(capi.load().mfcc_forward(self.plan._h, layout._h, _ptr(audio), code, _ptr(out), out.stride(0),
                                                 _OUT_KINDS[kind], _stream_ptr()))
+        return out
+
+    def _mfcc39_by_stages(self, audio, layout, out):
+        """MFCC-39 for the rare plan whose delta rows do not fit the general kernel's LDS (mfcc_plan_supports):
+        static rows in one launch, then delta and delta of delta per utterance (mfcc-self5.py:225-229)."""
+        nc, pf = self.plan.numcep, int(self.plan.cfg.pad_fac)
+        stat = self.forward(audio, layout, kind="static")
+        if out is None:
+            out = torch.empty((layout.total_frames, 3 * nc), dtype=torch.float32, device=audio.device)
+        lib = capi.load()
+        d = torch.empty_like(stat)
+        dd = torch.empty_like(stat)
+        with _on(self.plan.device, stat, out):
+            st = _stream_ptr()
+            fo = layout.frame_offsets
+            for u in range(layout.n_utts):
+                a, n = int(fo[u]), int(fo[u + 1] - fo[u])
+                if n:
+                    capi.check(lib.mfcc_delta(_ptr(stat[a:]), n, nc, pf, _ptr(d[a:]), st))
+                    capi.check(lib.mfcc_delta(_ptr(d[a:]), n, nc, pf, _ptr(dd[a:]), st))
+        out[:, :nc], out[:, nc:2 * nc], out[:, 2 * nc:3 * nc] = stat, d, dd
         return out
 
     def __call__(self, audio, lengths=None, out=None, kind="mfcc39"):
@@ -515,6 +538,15 @@ def cmvn_accumulate(feats, sums=None, static=False):
     with _on(feats.device, sums):
         capi.check(fn(_ptr(feats), feats.stride(0), n, d, _ptr(sums), _stream_ptr()))
     return sums
+
+
+def cmvn_release(device=None):
+    """Frees the partial-sum buffers cmvn_accumulate holds on ``device`` (one 16 MiB buffer per stream that
+    has called it).  Waits for the device first."""
+    dev = _device(device)
+    with torch.cuda.device(dev):
+        torch.cuda.synchronize(dev)
+        capi.check(capi.load().mfcc_cmvn_release())
 
 
 def cmvn_allreduce(sums, group=None):

@@ -36,3 +36,14 @@ def run_rank(rank, world, port, lengths, sample_utts, q):
     except Exception as exc:  # report instead of hanging the parent
         import traceback
         q.put((rank, 0, 0, "", None, None, None, None, traceback.format_exc() + repr(exc)))
+
+
+def run_command(cmd, cwd, q):
+    """Runs a command as a child of the fork server (a process that never held a HIP context, so starting
+    a program from it is allowed) and reports (exit code, stdout, stderr)."""
+    import subprocess
+    try:
+        r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=900)
+        q.put((r.returncode, r.stdout, r.stderr))
+    except Exception as exc:
+        q.put((-1, "", repr(exc)))

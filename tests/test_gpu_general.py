@@ -207,3 +207,39 @@ def test_layouts_and_plans_of_different_framings_do_not_mix(M):
         M.MFCC("self5", num_fft=500)          # not a power of two
     with pytest.raises(M.frontend.capi.MfccError):
         M.MFCC("self5", fs=30)                # int(30 * 0.010) = 0 samples per step
+
+
+def test_largest_tables_leave_no_room_for_delta_rows(M):
+    """2048-point FFT, 128 filters, 64 cepstra: the FFT buffers and filter rows fill a workgroup's LDS, so
+    the plan has no fused MFCC-39 (mfcc_plan_supports says so, mfcc_forward refuses it with a clear
+    error) but serves every other kind; the Python front-end builds MFCC-39 from the static rows and
+    mfcc_delta per utterance."""
+    import ctypes as C
+    from mfcc_amd import _capi as capi
+    a, b = _synth(91, 30000), _synth(92, 9000)
+    fe = M.MFCC("self5", fs=44100, frame_time=40, step_time=10, num_bins=128, numcep=64)
+    assert fe.plan.general and fe.plan.num_fft == 2048
+    lib = capi.load()
+    assert lib.mfcc_plan_supports(fe.plan._h, capi.OUT_MFCC39) == 0
+    assert lib.mfcc_plan_supports(fe.plan._h, capi.OUT_STATIC) == 1 and lib.mfcc_plan_supports(fe.plan._h, capi.OUT_SPEC) == 1
+    packed = torch.from_numpy(np.concatenate([a, b])).cuda()
+    lay = fe.layout([len(a), len(b)])
+    out = torch.zeros((lay.total_frames, 192), dtype=torch.float32, device="cuda")
+    rc = lib.mfcc_forward(fe.plan._h, lay._h, C.c_void_p(packed.data_ptr()), capi.AUDIO_I16, C.c_void_p(out.data_ptr()), 192,
+                          capi.OUT_MFCC39, None)
+    assert rc == capi.ERR_UNSUPPORTED and b"mfcc_delta" in lib.mfcc_last_error()
+    got = fe(packed, lengths=[len(a), len(b)]).cpu().numpy()
+    pos = 0
+    for x in (a, b):
+        _mag, pw, _w, nfft = O.winfft(O.preemphasis(x), fs=44100, frame_time=40, step_time=10, loop=False)
+        logmel, loge = O.melspec(pw, O.melbanks(44100, 128, 0, nfft), loop=False)
+        static = O.staticfeatures(loge, O.dctopt(O.dct_ortho(logmel, 64, loop=False), 22))
+        d = O.delta(static, loop=False)
+        ref = O.spectrograms(static, d, O.delta(d, loop=False))
+        assert_cep(got[pos:pos + ref.shape[0]], ref, "2048-point, 128 filters, 64 cepstra")
+        pos += ref.shape[0]
+    assert pos == got.shape[0]
+    # a long regression window on a small plan still fuses (numcep 13, pad_fac 14 was refused before)
+    fe2 = M.MFCC("self5", fs=44100, frame_time=40, step_time=10, num_bins=128, numcep=13, pad_fac=14)
+    assert lib.mfcc_plan_supports(fe2.plan._h, capi.OUT_MFCC39) in (0, 1)
+    fe2(a)

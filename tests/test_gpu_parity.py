@@ -366,6 +366,18 @@ def test_error_behaviour(M):
         M.MFCC("self5")(torch.zeros(10, dtype=torch.int16, device="cuda"), lengths=[10, 0])
     with pytest.raises(ValueError):
         M.MFCC("self5").forward(torch.zeros(10, dtype=torch.int16), None)
+    # a row stride beyond the specialised kernel's 32-bit row offsets is refused, not wrapped around
+    import ctypes as C
+    from mfcc_amd import _capi as capi
+    fe = M.MFCC("self5")
+    lay = fe.layout([4000])
+    a = torch.zeros(4000, dtype=torch.int16, device="cuda")
+    o = torch.zeros(64, dtype=torch.float32, device="cuda")
+    lib = capi.load()
+    rc = lib.mfcc_forward(fe.plan._h, lay._h, C.c_void_p(a.data_ptr()), capi.AUDIO_I16, C.c_void_p(o.data_ptr()), 7_100_000, capi.OUT_MFCC39, None)
+    assert rc == capi.ERR_UNSUPPORTED and b"32-bit row offsets" in lib.mfcc_last_error()
+    rc = lib.mfcc_forward(fe.plan._h, lay._h, C.c_void_p(a.data_ptr()), capi.AUDIO_I16, C.c_void_p(o.data_ptr()), 38, capi.OUT_MFCC39, None)
+    assert rc == capi.ERR_INVALID
 
 
 # --------------------------------------------------------------------------

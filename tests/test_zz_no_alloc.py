@@ -52,3 +52,74 @@ def test_static_scratch_entry_matches_allocating_entry():
     # the Python wrapper reaches the same entry point
     import mfcc_amd
     assert torch.equal(mfcc_amd.cmvn_accumulate(big, static=True), mfcc_amd.cmvn_accumulate(big))
+
+
+def test_static_entry_allocates_nothing_and_captures():
+    """The static entry point under stream capture (an allocation there would fail the capture), replayed on
+    new data; device memory in use does not move over a run of calls; calls from two streams take turns on
+    the shared array (each waits for the event of the call before it) and both give the allocating entry's bits."""
+    from mfcc_amd import _capi as capi
+    lib = capi.load()
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    feats = torch.randn(300007, 39, generator=gen, device="cuda")
+    ref = torch.zeros(79, dtype=torch.float64, device="cuda")
+    _call(lib.mfcc_cmvn_accumulate, feats, ref)
+    got = torch.zeros(79, dtype=torch.float64, device="cuda")
+    _call(lib.mfcc_cmvn_accumulate_static, feats, got)          # address resolved, event created: set-up is over
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        got.zero_()
+        _call(lib.mfcc_cmvn_accumulate_static, feats, got)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.equal(got, ref)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got.zero_()
+        _call(lib.mfcc_cmvn_accumulate_static, feats, got)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _call(lib.mfcc_cmvn_accumulate_static, feats, got)
+    got.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    feats2 = torch.randn(300007, 39, generator=gen, device="cuda") * 3
+    ref2 = torch.zeros(79, dtype=torch.float64, device="cuda")
+    _call(lib.mfcc_cmvn_accumulate, feats2, ref2)
+    feats.copy_(feats2)
+    got.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref2)
+    # eager calls after a capture still work (the event was never recorded into the graph), from two streams at once
+    a = torch.randn(200003, 39, generator=gen, device="cuda")
+    b = torch.randn(150001, 257, generator=gen, device="cuda")
+    ra, rb = torch.zeros(79, dtype=torch.float64, device="cuda"), torch.zeros(515, dtype=torch.float64, device="cuda")
+    _call(lib.mfcc_cmvn_accumulate, a, ra)
+    _call(lib.mfcc_cmvn_accumulate, b, rb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        ga, gb = torch.zeros_like(ra), torch.zeros_like(rb)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            _call(lib.mfcc_cmvn_accumulate_static, a, ga)
+        with torch.cuda.stream(s2):
+            _call(lib.mfcc_cmvn_accumulate_static, b, gb)
+        torch.cuda.synchronize()
+        assert torch.equal(ga, ra) and torch.equal(gb, rb)
+
+
+def test_workspace_of_the_allocating_entry_is_released():
+    import mfcc_amd
+    x = torch.randn(4096, 39, device="cuda")
+    mfcc_amd.cmvn_accumulate(x)
+    torch.cuda.synchronize()
+    held = torch.cuda.mem_get_info()[0]
+    mfcc_amd.cmvn_release()
+    assert torch.cuda.mem_get_info()[0] >= held + (15 << 20)     # the 16 MiB buffer of this stream went back
+    assert torch.equal(mfcc_amd.cmvn_accumulate(x), mfcc_amd.cmvn_accumulate(x, static=True))
