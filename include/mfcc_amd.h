@@ -162,8 +162,12 @@ int32_t mfcc_out_width(const mfcc_plan* plan, int32_t out_kind);
  * (MLP_5hidlayer_40.py:70-105): out[t, f*B + c] = spec[clamp(t + f - (N-1)/2, 0, F_u - 1), c], B = nfft/2+1.
  * Every spectrum row is computed once, kept in LDS, and each output row leaves as one contiguous write.
  * out: [total_frames, framenum * B] contiguous floats, 16-byte aligned; out_kind MFCC_OUT_SPEC or
- * MFCC_OUT_LOGSPEC; framenum = 1, 5, 9, 13 or 17 (MFCC_ERR_UNSUPPORTED otherwise: use mfcc_forward +
- * mfcc_stack_context, which take any odd framenum and any feature width). */
+ * MFCC_OUT_LOGSPEC; framenum odd, 1 .. 21 (the reference's scripts use 7 .. 21, MLP_5hidlayer_40.py:244-262;
+ * MFCC_ERR_UNSUPPORTED beyond: use mfcc_forward + mfcc_stack_context, which take any odd framenum and any
+ * feature width).  Windows of 19 and 21 frames keep more spectrum rows in LDS and run one workgroup per CU.
+ * out_kind MFCC_OUT_MFCC39 stacks the finished feature rows instead (coeffs = 39, e.g. framenum = 11, the
+ * reference's best model, nn_model_statistics.csv:13): out[t, f*D + j] = mfcc39[clamp(t + f - (N-1)/2, 0, F_u - 1), j],
+ * D = 3*numcep, out [total_frames, framenum * D]; framenum odd, 3 .. 21; plans of the specialised kernel. */
 int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype,
                          int32_t framenum, float* out, int32_t out_kind, void* stream);
 

@@ -6,11 +6,11 @@ mfcc-self15.py, MLP_5hidlayer_40.py) backed by HIP kernels, plus the fused batch
 from .frontend import (  # noqa: F401
     MFCC, Layout, Plan, StreamingMFCC, VARIANTS, cmvn_accumulate, cmvn_allreduce, cmvn_apply, cmvn_constants, cmvn_release, coeffs, dctopt, delta,
     delta_factor, duration, frame_time, fs, get_plan, lift_factor, loadPatData, loadrawdata, low_freq, melbanks,
-    melspec, mfcc, mfcc39, num_bins, num_fft, padUtterance, preemphasis, shard_utterances, slidingWin, spectrograms,
+    melspec, mfcc, mfcc39, mfcc39_stack, num_bins, num_fft, padUtterance, preemphasis, shard_utterances, slidingWin, spectrograms,
     spectrum257, spectrum_stack, stack_context, staticfeatures, step_time, winfft, writePatData)
 
 __all__ = [
-    "MFCC", "Layout", "Plan", "StreamingMFCC", "VARIANTS", "mfcc39", "spectrum257", "spectrum_stack", "stack_context", "cmvn_accumulate", "cmvn_release",
+    "MFCC", "Layout", "Plan", "StreamingMFCC", "VARIANTS", "mfcc39", "mfcc39_stack", "spectrum257", "spectrum_stack", "stack_context", "cmvn_accumulate", "cmvn_release",
     "cmvn_allreduce", "cmvn_constants", "cmvn_apply", "shard_utterances", "get_plan",
     # reference names
     "loadrawdata", "preemphasis", "winfft", "melbanks", "melspec", "mfcc", "dctopt", "staticfeatures", "delta",

@@ -14,10 +14,12 @@
 //               2. each wave transforms 4 frames, 16 lanes per frame (fft_lane.h), and leaves
 //                  the 257 spectrum values of each frame in LDS;                [barrier]
 //               3. the [filters x 257] x [257 x 16 frames] filterbank product runs as matrix
-//                  instructions (v_mfma_f32_16x16x4_f32, an exact f32 fma chain): every wave owns
-//                  a group of filters, takes ln of its sums at once and feeds them, still in
-//                  registers, to its share of the [numcep x filters] DCT*lifter product; the
-//                  four shares go to a small LDS tile;                            [barrier]
+//                  instructions on 4x4 blocks (v_mfma_f32_4x4x1_16b_f32, an exact f32 fma chain):
+//                  the filters are cut into groups of four, whose weights cover a short range of
+//                  bins (the bank is a band matrix); every wave owns some of the groups, takes the
+//                  logarithm of its sums at once and feeds them, still in registers, to its share
+//                  of the [numcep x filters] DCT*lifter product; the four shares go to a small
+//                  LDS tile;                                                      [barrier]
 //               4. the shares are summed, c0 := ln E, and the static row enters a ring of 32
 //                  rows in LDS.
 //   rows out  one batch later, when the rows t-4 .. t+4 of a frame exist, delta and delta-delta
@@ -25,9 +27,11 @@
 //             output line is written once, nothing is read back (4 halo frames are computed on
 //             each side of a tile where the utterance continues).
 //
-// On gfx950 the fp32 matrix instruction runs on the vector ALU's pipe (a wave mix of both takes
-// the sum of their times), so every k-step counts like ~7 vector instructions: the plan splits
-// the filters so that the waves need few k-steps and the kernel skips those a wave does not need.
+// On gfx950 the fp32 matrix instructions run on the vector ALU's pipe (a wave mix of both takes
+// the sum of their times) at 32 multiply-adds per cycle whatever their shape, so what counts is
+// how many of an instruction's multiply-adds meet a non-zero weight.  A bin feeds two filters
+// (mfcc-self5.py:102-117): in a 4-filter block half of the products are useful, in the
+// 16-filter block of v_mfma_f32_16x16x4_f32 an eighth.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -77,8 +81,8 @@ constexpr int kHalo = 4;          // delta-delta reach: 2 * pad_fac
 constexpr int kMaxCep = 16;
 constexpr int kMaxMel = 40;       // "26-40 Mel bins" (mfcc-self5.py:23); bounds the LDS tables
 constexpr int kStage = (kBatch - 1) * kFrameStep + kFrameSize;  // 2800 samples per batch
-constexpr int kMelCols = 15;      // filter columns per wave; column 15 carries the wave's energy partial
-constexpr int kMelSteps = 24;     // MFMA k-steps (4 bins each) every wave runs
+constexpr int kMelGroups = kMaxMel / 4;  // filter groups (up to four filters each: the rows of a 4x4 block) at most
+constexpr int kMelQuads = 6;      // slots of four filterbank k-steps (16 bins) a wave runs at most
 
 // LDS carve (floats).
 constexpr int kSlot = 512;                           // LDS floats per frame slot: the 2 KiB exchange buffer of a frame
@@ -86,22 +90,28 @@ constexpr int kSlot = 512;                           // LDS floats per frame slo
 // floats, so rows stay 16-byte aligned) serves both access patterns of the rows without bank
 // conflicts: the untangle writes 16 consecutive columns from each of a wave's 4 frames with
 // ds_write_b32 (rows 4w and 4w+1, resp. 4w+2 and 4w+3, share an instruction half: their skews
-// differ by 16 banks), the filterbank reads 16 bytes per lane with ds_read_b128, whose 16-lane
-// groups hold rows {0-3, 12-15} at one column block and rows {4-11} at the next: both row sets
-// map onto the 8 even 16-byte slots.
-__host__ __device__ constexpr int row_skew(int r) { return 32 * ((r >> 3) & 1) + 16 * (r & 1) + 8 * ((r >> 1) & 1); }
+// differ by 16 banks); the filterbank reads 16 bytes per lane with ds_read_b128, lane
+// 16 a + 4 b + c taking row 4 a + c at 16-byte column block b: the instruction's 16-lane groups
+// {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} then hold blocks {0, 3} of rows 0-3 with blocks
+// {1, 2} of rows 4-7, resp. the other way round -- with the rows of a group of four 64 bytes
+// apart, each lane group covers all sixteen 16-byte slots of the 64 banks once.
+__host__ __device__ constexpr int row_skew(int r) { return 16 * (r & 3); }
 constexpr int kRowPad = 260;                         // bins 0..256 plus zeros up to a multiple of 4
 constexpr int kXbufFloats = kBatch * kSlot;          // exchange buffers (fb*512) / spectrum rows
 constexpr int kAbufFloats = 2808;                    // staged audio: kStage + up to 7 alignment samples, whole chunks
 // Partial DCT sums (one share per wave, the filters it owns) of frame slot i live in the upper part
 // of that slot's 2 KiB (the spectrum row ends below float 320, the exchange of the next transform
 // is written by the very wave that reads the shares, later in its program): coefficient c of wave w
-// at float kPartBase + ((16 w + (c & ~3) + 4 i) mod 64) + (c & 3) -- a lane's four coefficients are one
-// 16-byte write, and the eight frames of a write group land on 32 different banks -- and the wave's
-// share of the frame's energy sum at kPartEnergy + w.
+// at float kPartBase + ((16 w + (c & ~3) + rot(i)) mod 64) + (c & 3), rot = 0, 16, 8, 24 for i mod 4 =
+// 0..3 -- a lane's four coefficients are one 16-byte write, the eight lanes of a write group (two
+// coefficient blocks of four frames) land on 32 different banks, and the two frames whose sixteen
+// coefficients one half of a ds_read_b32 collects lie 16 banks apart -- and the frame's energy sum
+// (formed beside the transform) at kPartEnergy.
 constexpr int kPartBase = 320, kPartEnergy = 384;
-static_assert(56 + kRowPad <= kPartBase, "the shares of a frame slot start behind its spectrum row");
-__host__ __device__ constexpr int part_index(int slot, int w, int c) { return slot * kSlot + kPartBase + ((16 * w + (c & ~3) + 4 * slot) & 63) + (c & 3); }
+static_assert(48 + kRowPad <= kPartBase, "the shares of a frame slot start behind its spectrum row");
+__host__ __device__ constexpr int part_index(int slot, int w, int c) {
+  return slot * kSlot + kPartBase + ((16 * w + (c & ~3) + 16 * (slot & 1) + 8 * ((slot >> 1) & 1)) & 63) + (c & 3);
+}
 // Ring of static-feature rows for the delta / delta-delta regression: row t of the tile sits at
 // ring row (t - s_lo + 8) mod 32; ring rows 0..7 are mirrored at 32..39 so that the 9 rows
 // t-4 .. t+4 a lane reads are always consecutive.
@@ -114,22 +124,32 @@ constexpr int ring_rows(int ring_pitch) { return ring_pitch > 13 ? 32 : kRingRow
 constexpr int kTwPitch = 52;
 constexpr int kTwUnt = 0, kTwSt1 = 8;                // complex index of the first untangle / stage-1 value
 constexpr int kTwFloats = 16 * kTwPitch;
+// DCT * lifter weights of the chained product, A operands of v_mfma_f32_4x4x1_16b_f32: group g at
+// float 64 g, 16 bytes per lane index (lane & 15)
+constexpr int kDctFloats = kMelGroups * 64;
+// Stacked MFCC-39 kind: ring of finished rows (3 numcep floats each, back to back): row r of the tile's rows at
+// ring row (r - first) mod 64, rows 0 .. kStackMaxN - 2 repeated behind row 63 so that the N rows of a context
+// window are always one contiguous run of floats.
+constexpr int kORows = 64;
+constexpr int oring_floats(int ncep) { return (kORows + 20) * 3 * ncep; }
 // ring_pitch = floats per ring row: numcep where it is a compile-time constant, else kMaxCep
-constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + ring_rows(ring_pitch) * ring_pitch + kTwFloats; }
+constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + ring_rows(ring_pitch) * ring_pitch + kTwFloats + kDctFloats; }
 // Stacked spectrum kinds: instead of the partial-DCT tiles and the statics ring, a ring of the last
-// 32 spectrum rows (frame s of the tile at ring row (s - s_lo) mod 32, 257 values behind a phase of
-// 0..3 floats), from which whole output rows are written.  81 632 bytes: two workgroups per CU
-// (the kernel is bound by its stores; the transforms of one workgroup hide under the stores of the other).
-constexpr int kSRingRows = 32;
+// spectrum rows (frame s of the tile at ring row (s - s_lo) mod rows, 257 values behind a phase of
+// 0..3 floats), from which whole output rows are written.  The ring holds the 2 * (N / 2) frames a row
+// reaches back plus the batch being transformed: 32 rows for windows of up to 17 frames (81 632 bytes:
+// two workgroups per CU -- the kernel is bound by its stores; the transforms of one workgroup hide
+// under the stores of the other), 64 rows for 19 and 21 frames (one workgroup per CU).
 constexpr int kSRingPitch = 268;
-constexpr int kStackMaxN = 17;                        // context windows up to 17 frames: 2 * (N / 2) + 16 <= kSRingRows
-constexpr int smem_floats_stacked() { return kXbufFloats + kAbufFloats + kSRingRows * kSRingPitch + kTwFloats; }
-static_assert(smem_floats_stacked() * 4 <= 64 * 1280, "stacked kinds no longer fit two workgroups per CU");
-static_assert(2 * (kStackMaxN / 2) + kBatch <= kSRingRows, "spectrum ring too short for the context window");
+constexpr int kStackMaxN = 21;                        // odd framenum values of the reference's scripts: 7 .. 21
+static_assert(kStackMaxN - 1 == 20, "oring_floats() keeps kStackMaxN - 1 mirror rows");
+constexpr int stack_ring_rows(int n) { return 2 * (n / 2) + kBatch <= 32 ? 32 : 64; }
+constexpr int smem_floats_stacked(int n) { return kXbufFloats + kAbufFloats + stack_ring_rows(n) * kSRingPitch + kTwFloats; }
+static_assert(smem_floats_stacked(17) * 4 <= 64 * 1280, "stacked kinds with windows up to 17 frames no longer fit two workgroups per CU");
+static_assert(2 * (kStackMaxN / 2) + kBatch <= stack_ring_rows(kStackMaxN), "spectrum ring too short for the context window");
 // gfx950 hands out LDS in units of 1280 bytes; three workgroups per CU fit while each takes at
 // most 42 units of the CU's 128.  The 13-coefficient kernels meet that exactly.
 static_assert(smem_floats(13) * 4 <= 42 * 1280 && smem_floats(kMaxCep) * 4 <= 42 * 1280, "LDS carve no longer allows three workgroups per CU");
-static_assert(kMelCols == 15, "filter slot 15 of a wave carries its energy partial");
 static_assert((kBatch - 1) * 512 + row_skew(kBatch - 1) + kRowPad <= kXbufFloats, "spectrum rows fit in the exchange buffer");
 
 constexpr float kEps64 = 2.220446049250313e-16f;     // np.finfo(float).eps, mfcc-self5.py:131
@@ -146,28 +166,37 @@ struct Tile {
   int32_t pad;
 };
 
-// How the [16 frames x 257 bins] x [257 x (nmel + energy)] filterbank product is cut for
-// v_mfma_f32_16x16x4_f32: wave w owns filters first_filter[w] .. +nfilt[w]-1 in columns
-// 0..14 of its 16x16 result and a partial energy sum in column 15, and walks kMelSteps 4-bin
-// k-steps starting at bin kstart[w] (steps it does not need carry zero weights).
+// How the [filters x 257 bins] x [257 x 16 frames] filterbank product is cut for
+// v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per instruction).  The filters form
+// groups of up to four consecutive ones (four each, unless the filters are so wide that a group has to
+// be split to fit a wave's slots); a group's weights are non-zero on a short range of bins, which starts at a multiple of four and is walked in QUADS of four
+// k-steps = 16 bins.  In a k-step, block 4 a + b of the instruction (lanes 16 a + 4 b .. + 3) multiplies
+// the group's four weights of ONE bin with that bin's values of frames 4 a .. 4 a + 3: k-step st of
+// quad i takes bin k0 + 16 i + 4 b + st for b = 0..3, so the four blocks of a 16-lane row split the
+// range between them (their sums meet by two row rotations) and a lane's four k-steps of a quad
+// are 16 contiguous bytes of its frame's spectrum row.  Every wave owns some groups; its quads,
+// group after group, fill SLOTS 0 .. nslots-1, each described by one word:
+//   bits 0-5   first bin of the quad / 4            bit 6   first quad of its group
+//   bit 7      last quad of its group               bits 8-10  filters in the group (1..4)
+//   bits 11-16 first filter of the group            bits 17-20 group number (its DCT weights)
 struct MelMap {
-  int32_t kstart[4];
-  int32_t first_filter[4];
-  int32_t nfilt[4];
-  int32_t ndct;  // k-steps of the DCT product = ceil(nmel / 4)
+  int32_t nslots[4];
+  uint32_t slot[4][kMelQuads];
 };
+constexpr uint32_t kSlotFirst = 1u << 6, kSlotLast = 1u << 7;
 
 // Per-plan constants, resident in device memory; read with scalar loads where needed so
 // that they do not occupy scalar registers across the batch loop.
 struct PlanConst {
   const float* tw512;     // [512][2]  exp(-2 pi i m / 512)
-  const float* melB;      // [4][kMelSteps/4][64][4] B operands (filter weights * spec_scale): 16 B per lane and 4 k-steps
-  const float* dctA;      // [4 waves][64][4] per-wave DCT*lifter weights of the chained product, times ln 2 (the kernel
-                          //   feeds it log2 of the mel sums): lane (c = lane & 15, g = lane >> 4), element r = weight of
-                          //   (filter first_filter[w] + g + 4 r, coefficient c)
+  const float* melW;      // [4 waves][kMelQuads][16][4] A operands of the filterbank (filter weights * spec_scale): lane
+                          //   index 4 b + i (= lane & 15), element st = weight of filter (group's first + i) at the bin of
+                          //   block b in k-step st of the slot's quad
+  const float* dctW;      // [kMelGroups][16][4] DCT*lifter weights of the chained product, times ln 2 (the kernel feeds
+                          //   it log2 of the mel sums): lane index 4 b + i, element r = weight of (coefficient 4 b + i,
+                          //   filter r of group g)
   const float* window;    // [512] or nullptr
   MelMap map;
-  int32_t mel_steps[4];   // k-steps wave w really needs (<= kMelSteps)
   int32_t nmel;
   int32_t numcep;
   float pre_hi, pre_lo;   // pre-emphasis coefficient split in two floats (hi + lo ~ double value); 0, 0 = off
@@ -261,7 +290,7 @@ struct FusedParams {
   float* out;
   int64_t out_ld;
   const PlanConst* pc;
-  int32_t stack_n;            // stacked kinds: frames per context window N (N % 4 == 1); out_ld = N * bins
+  int32_t stack_n;            // stacked kinds: frames per context window N (odd, <= kStackMaxN); out_ld = N * bins
   StreamArgs stream;          // streaming kind only
 #ifdef MFCC_DIAG
   unsigned long long* dbg;    // [n_tiles][4 waves][8] cycle sums
@@ -281,7 +310,11 @@ enum : int { kOutMfcc39 = 0, kOutStatic = 1, kOutLogmel = 2, kOutSpec = 3, kOutL
              // One push of B live streams in one launch, workgroup b = stream b: append the chunk to the
              // stream's segment, static rows of the new complete frames (as kOutStatic, into the stream's
              // row store), then the output rows whose +-4-frame context is complete.
-             kOutStream = 7 };
+             kOutStream = 7,
+             // MFCC-39 rows stacked over N frames, out[t, f * 3 ncep + j] = row[clamp(t + f - N / 2)][j] (padUtterance +
+             // slidingWin with coeffs = 39, MLP_5hidlayer_40.py:70-105): the finished rows pass through a ring in
+             // LDS, from which whole output rows are written
+             kOutMfcc39Stack = 8 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -309,6 +342,13 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 
 __device__ __forceinline__ float lane_read(int byte_addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+
+// v[lane] of the lane N places further on in its row of 16 lanes (row_ror:N): adding the results for
+// N = 8, 4 (and 2, 1) leaves every lane with the sum over the lanes of its row that differ in those bits.
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
 }
 
 // Staging of one 16-frame batch into LDS as float, pre-emphasised, zero beyond the utterance
@@ -453,12 +493,17 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const abuf = xbuf + kXbufFloats;
   // floats per row of the statics ring; only the MFCC-39 kind has one (the others would carry 2.5 KB
   // of LDS they never touch, one allocation unit too many for three workgroups per CU)
-  constexpr int RP = OUT == kOutMfcc39 ? (NCEP > 0 ? NCEP : kMaxCep) : 0;
+  constexpr bool kRows39 = (OUT == kOutMfcc39 || OUT == kOutMfcc39Stack);  // kinds that form delta and delta-delta rows
+  constexpr int RP = kRows39 ? (NCEP > 0 ? NCEP : kMaxCep) : 0;
   constexpr bool kStack = (OUT == kOutSpecStack || OUT == kOutLogspecStack);
   float* const ring = abuf + kAbufFloats;
   float* const sring = abuf + kAbufFloats;  // stacked kinds: ring of spectrum rows in place of part / ring
   constexpr bool kMirror = ring_rows(RP) > 32;  // ring rows 0..7 repeated behind row 31
-  float* const twl = kStack ? sring + kSRingRows * kSRingPitch : ring + ring_rows(RP) * RP;
+  const int srow_mask = kStack ? stack_ring_rows(p.stack_n) - 1 : 0;  // stacked kinds: rows of the spectrum ring - 1
+  const int stack_sign = (p.stack_n & 2) ? -1 : 1;  // N % 4 == 3: an output row's N * 257 floats are congruent to -1 mod 4
+  float* const twl = kStack ? sring + (srow_mask + 1) * kSRingPitch : ring + ring_rows(RP) * RP;
+  float* const dctl = twl + kTwFloats;  // DCT * lifter weights (not in the stacked spectrum kinds' carve)
+  float* const oring = dctl + kDctFloats;  // kOutMfcc39Stack: ring of finished rows
 
   constexpr bool kSpecOut = (OUT == kOutSpec || OUT == kOutLogspec || kStack);
   constexpr bool kLogOut = (OUT == kOutLogspec || OUT == kOutLogspecStack);
@@ -497,26 +542,30 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   // frames this tile computes: its own, plus what the rows at its ends reach for where the utterance
   // continues (4 frames for delta-delta, half a context window for the stacked kinds)
   // (a stacked row also completes the 16-byte chunk it shares with the row before it: one frame back at least)
-  const int reach = (OUT == kOutMfcc39) ? kHalo : (kStack ? p.stack_n >> 1 : 0);
+  const int reach = (OUT == kOutMfcc39) ? kHalo : (OUT == kOutMfcc39Stack ? kHalo + (p.stack_n >> 1) : (kStack ? p.stack_n >> 1 : 0));
   const int s_lo = (reach || kStack) ? max(0, t0 - max(reach, kStack ? 1 : 0)) : t0;
   const int s_hi = (reach || kStack) ? min(nframes, t0 + nt + reach) : t0 + nt;
   const int nmel = pc->nmel;
   const int ncep = NCEP > 0 ? NCEP : pc->numcep;
+  // kOutMfcc39Stack: rows o_lo .. o_hi - 1 of the utterance pass through the ring of finished rows
+  const int o_lo = OUT == kOutMfcc39Stack ? max(0, t0 - (p.stack_n >> 1)) : 0;
+  const int o_hi = OUT == kOutMfcc39Stack ? min(nframes, t0 + nt + (p.stack_n >> 1)) : 0;
   const int ld = (int)p.out_ld;
   float* const out_t0 = p.out + (f_off + t0) * p.out_ld;  // row t0 of this tile; 32-bit offsets from here
   const float pre_hi = pc->pre_hi, pre_lo = pc->pre_lo;
   const bool mag = pc->spectrum != 0;
   // plan constants of the spectrum kinds, read here, before any store of the kernel: inside the batch
   // loop they would be vector loads behind the staging loads on the in-order memory counter
-  const float spec_scale = kSpecOut ? pc->spec_scale : 0.f, spec_floor = kSpecOut ? pc->log_floor : 0.f;
-  const bool half_band = kSpecOut && pc->decim == 2;
+  const float spec_scale = pc->spec_scale, spec_floor = kSpecOut ? pc->log_floor : 0.f;
+  const bool half_band = pc->decim == 2;  // a 256-point plan: the even bins of the 512-point transform
   const gfloat_ptr window = as_global(pc->window);
-  // this wave's share of the filterbank product
-  const int mel_k0 = pc->map.kstart[wave], mel_nf = pc->map.nfilt[wave], mel_ff = pc->map.first_filter[wave];
-  const int mel_groups = (pc->mel_steps[wave] + 3) >> 2;  // groups of four k-steps this wave needs (wave-uniform)
+  // this wave's share of the filterbank product: its slots of four k-steps (see MelMap), wave-uniform
+  const int mel_nslots = pc->map.nslots[wave];
+  unsigned slot_info[kMelQuads];
+#pragma unroll
+  for (int s = 0; s < kMelQuads; ++s) slot_info[s] = pc->map.slot[wave][s];
   typedef const f32x4 __attribute__((address_space(1))) * gfloat4_ptr;
-  const gfloat4_ptr melB4 = (gfloat4_ptr)(uintptr_t)pc->melB + (wave * (kMelSteps / 4)) * 64 + lane;
-  static_assert(kMelSteps % 4 == 0, "filterbank operands are fetched four k-steps at a time");
+  const gfloat4_ptr melW4 = (gfloat4_ptr)(uintptr_t)pc->melW + (wave * kMelQuads) * 16 + (lane & 15);
 
   // Twiddles per lane index q: stage 1 uses W256^(q k1) = W512^(2 q k1), k1 = 1..15, the
   // untangle W512^(q + 16 s), s = 0..7.  They live in LDS (row q, 23 complex values) and are
@@ -529,6 +578,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       const int slot = k < 15 ? kTwSt1 + k : kTwUnt + (k - 15);
       *(cf*)(twl + qq * kTwPitch + 2 * slot) = mk(tw[2 * m], tw[2 * m + 1]);
     }
+  }
+  if (!kSpecOut) {
+    const gfloat_ptr dwg = as_global(pc->dctW);
+    for (int i = tid; i < kDctFloats; i += 256) dctl[i] = dwg[i];
   }
   const cf* const twq = (const cf*)(twl + q * kTwPitch);
   const int partner_addr = ((lane & 48) | partner_lane(q)) << 2;
@@ -544,12 +597,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const bool floor_mel = pc->floor_mel != 0;
 
   stage_ld(s_lo);
-  // DCT*lifter weights of this wave's filter group (A operand of the chained product), 4 registers
-  f32x4 dw;
-  {
-    typedef const f32x4 __attribute__((address_space(1))) * gf4;
-    dw = ((gf4)(uintptr_t)pc->dctA)[wave * 64 + lane];
-  }
   int delta = stage_st(s_lo);
   __syncthreads();
 
@@ -608,7 +655,22 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       d[3] = u == 0 ? e[2] : e[3];                          // row r+1 beyond the last row
       d[4] = u == 0 ? e[2] : (u == 1 ? e[3] : e[4]);
     }
-    if (q < ncep && r >= t0 && r < t0 + nt) {
+    if (OUT == kOutMfcc39Stack) {
+      if (q < ncep && r >= o_lo && r < o_hi) {
+        const int slot = (r - o_lo) & (kORows - 1);
+        float* const o = oring + slot * (3 * ncep) + q;
+        const float dd = regress(d[0], d[1], d[2], d[3], d[4]);
+        o[0] = v[4];
+        o[ncep] = d[2];
+        o[2 * ncep] = dd;
+        if (slot < p.stack_n - 1) {  // mirror behind the ring's last row
+          float* const om = o + kORows * (3 * ncep);
+          om[0] = v[4];
+          om[ncep] = d[2];
+          om[2 * ncep] = dd;
+        }
+      }
+    } else if (q < ncep && r >= t0 && r < t0 + nt) {
       float* const o = out_t0 + (r - t0) * ld + q;
       o[0] = v[4];
       o[ncep] = d[2];
@@ -616,18 +678,66 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     }
   };
 
+  // ---- kOutMfcc39Stack: whole output rows from the ring of finished rows ---------------------------------
+  // out[t, f OP + j] = row[clamp(t + f - h)][j], OP = 3 numcep, W = N OP floats per output row.  Rows
+  // below rows_done are in the ring.  One wave writes a whole output row front to back as aligned 16-byte
+  // chunks (chunk ch = the row's floats 4 ch - a .. 4 ch - a + 3, a = the row's offset from a 16-byte
+  // boundary; a chunk belongs to the row that holds its last float, so the first chunk of a row also
+  // carries the last a floats of the row before it).  Away from the utterance's ends the window's N rows
+  // are one contiguous run in the ring; near them every float is looked up on its own.
+  int stack_next = t0;  // stacked kinds: first output row not yet written
+  auto write_stack_rows = [&](int rows_done) {
+    const int N = p.stack_n, hN = N >> 1, OP = 3 * ncep, W = N * OP;
+    const int t_end = min(rows_done >= nframes ? nframes : rows_done - hN, t0 + nt);
+    auto row_at = [&](int sfrm) { return oring + ((min(max(sfrm, 0), nframes - 1) - o_lo) & (kORows - 1)) * OP; };
+    for (int t = stack_next + wave; t < t_end; t += 4) {
+      const int a = (int)(((f_off + t) * (int64_t)W) & 3);
+      float* const orow = p.out + (f_off + t) * (int64_t)W;
+      float* const obase = orow - a;  // 16-byte aligned
+      const bool interior = t >= hN && t + hN <= nframes - 1;
+      const int ch_hi = (W + a - 4) >> 2;
+      const float* const win = oring + ((t - hN - o_lo) & (kORows - 1)) * OP - a;  // interior rows: float g of the row at win[a + g]
+      for (int ch = lane; ch <= ch_hi; ch += 64) {
+        f32x4 v;
+        if (interior && ch > 0) {
+          const float* const src = win + 4 * ch;
+          v = f32x4{src[0], src[1], src[2], src[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int g = 4 * ch - a + e, tt = t;
+            if (g < 0) { g += W; tt = t - 1; }  // tail of the row before
+            const int f = g / OP, j = g - f * OP;
+            v[e] = row_at(tt + f - hN)[j];
+          }
+        }
+        if (t == 0 && ch == 0 && a > 0) {  // first row of the utterance: the floats in front belong to another utterance
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e >= a) obase[e] = v[e];
+        } else {
+          *(f32x4*)__builtin_assume_aligned(obase + 4 * ch, 16) = v;
+        }
+      }
+      if (t == nframes - 1) {  // last row of the utterance: nobody follows to complete its last chunk
+        const int ntail = (a + W) & 3;
+        if (lane < ntail) orow[W - ntail + lane] = row_at(nframes - 1)[OP - ntail + lane];
+      }
+    }
+    stack_next = max(stack_next, t_end);
+  };
+
 #ifdef MFCC_DIAG
   unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   MFCC_STAMP(tk0);
 #endif
-  int stack_next = t0;  // stacked kinds: first output row not yet written
   for (int tb = s_lo; tb < s_hi; tb += kBatch) {
     MFCC_STAMP(ta);
     __builtin_amdgcn_s_setprio(MFCC_PRIO_FFT);
     // spectrum kinds have no filterbank phase to cover the staging loads of the next batch: they fly
     // during this batch's transforms instead
     if (kSpecOut && !kStack) stage_ld(tb + kBatch);
-    float bv[kMelSteps];  // B operands of this wave's filterbank k-steps, fetched at the end of the FFT section
+    f32x4 bv[kMelQuads];  // filter weights of this wave's slots (A operands), fetched at the end of the FFT section
     // ---- FFT-512 of 4 frames per wave, 16 lanes per frame -----------------------------
     {
       const float* fa = abuf + delta + fb * G::kStep;
@@ -739,16 +849,15 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       if (!kSpecOut) {
         // fetch the filterbank operands of this wave now (L2 latency ~ the untangle below)
 #pragma unroll
-        for (int s = 0; s < kMelSteps; s += 4) {
-          const f32x4 w4 = melB4[(s / 4) * 64];
-          bv[s] = w4.x; bv[s + 1] = w4.y; bv[s + 2] = w4.z; bv[s + 3] = w4.w;
-        }
+        for (int s = 0; s < kMelQuads; ++s) bv[s] = melW4[s * 16];
       }
-      // Stacked kinds keep the finished spectrum rows in a ring in LDS, each shifted by the 16-byte
-      // phase (0..3 floats) its copies will have in the output, so that the row writer below moves
-      // aligned 16-byte chunks: element c of frame s lands at output float (f_off + t) N B + f B + c
-      // with s = t + f - h, which is congruent to f_off + s + h + c mod 4 for B = 257 and N % 4 == 1.
-      float* const P = kStack ? sring + ((tb + fb - s_lo) & (kSRingRows - 1)) * kSRingPitch + (int)((f_off + tb + fb + (p.stack_n >> 1)) & 3)
+      // Stacked kinds keep the finished spectrum rows in a ring in LDS, each shifted by a phase of 0..3
+      // floats so that the row writer below moves aligned chunks: element c of frame s lands at output float
+      // (f_off + t) N B + f B + c with s = t + f - h, which for B = 257 is congruent mod 4 to
+      // f_off + s + h + c when N % 4 == 1 and to s + h - f_off + c - 2 t when N % 4 == 3: with the phase
+      // (+-f_off + s + h) mod 4 every chunk of the first case starts on a 16-byte boundary of the ring, and
+      // those of the second on an 8-byte boundary (rows with odd t sit two floats off).
+      float* const P = kStack ? sring + ((tb + fb - s_lo) & srow_mask) * kSRingPitch + (int)((stack_sign * f_off + tb + fb + (p.stack_n >> 1)) & 3)
                               : xbuf + fb * 512 + row_skew(fb);
       // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
       float* const spec_row = (kSpecOut && !kStack && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
@@ -758,6 +867,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         if (kLogOut) v = fast_ln(fmaxf(v, spec_floor));  // floor 0 = none: ln 0 = -inf as np.log
         return v;
       };
+      // the frame's energy sum (mfcc-self5.py:130) is collected on the way: every bin passes through
+      // exactly one lane of the frame here
+      cf esum = mk(0.f, 0.f);
       // Z[256-k] lives in the partner lane: fetch four partners and four untangle twiddles at
       // a time, so that their latencies overlap instead of adding up
 #pragma unroll
@@ -816,6 +928,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           for (int s = 0; s < 4; ++s) {
             P[q + 16 * (h + s)] = lo4[s];
             P[256 - q - 16 * (h + s)] = hi4[s];
+            esum = esum + mk(lo4[s], hi4[s]);
           }
         }
       }
@@ -826,9 +939,21 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           if (spec_row) spec_row[half_band ? 64 : 128] = spec_value(4.f * norm2(x[8]));
         } else {
           const float p128 = 4.f * norm2(x[8]);
-          P[128] = mag ? __builtin_amdgcn_sqrtf(p128) : p128;
-          P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last MFMA k-steps
+          const float v128 = mag ? __builtin_amdgcn_sqrtf(p128) : p128;
+          P[128] = v128;
+          P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last k-steps
+          esum.x += v128;
         }
+      }
+      if (!kSpecOut) {
+        // sum over the frame's 16 lanes; a 256-point plan counts the even bins only (a lane's bins have the parity of q)
+        float e = esum.x + esum.y;
+        if (half_band && (q & 1)) e = 0.f;
+        e += row_ror<8>(e);
+        e += row_ror<4>(e);
+        e += row_ror<2>(e);
+        e += row_ror<1>(e);
+        if (q == 0) xbuf[fb * kSlot + kPartEnergy] = e;
       }
     }
 #if !defined(MFCC_ABL_STAGE) && defined(MFCC_EARLY_STAGE)
@@ -858,9 +983,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       const int done = min(tb + kBatch, s_hi);  // frames 0 .. done-1 of the utterance are (or were) in the ring
       const int t_end = min(done == nframes ? nframes : done - hN, t0 + nt);
       typedef float f32x4_t __attribute__((ext_vector_type(4)));
-      auto ring_row = [&](int sfrm) { return sring + ((sfrm - s_lo) & (kSRingRows - 1)) * kSRingPitch + (int)((f_off + sfrm + hN) & 3); };
+      auto ring_row = [&](int sfrm) { return sring + ((sfrm - s_lo) & srow_mask) * kSRingPitch + (int)((stack_sign * f_off + sfrm + hN) & 3); };
+      const bool half_aligned = stack_sign < 0;  // N % 4 == 3: chunks lie on 8-byte boundaries of the ring rows
       for (int t = stack_next + wave; t < t_end; t += 4) {
-        const int a = (int)((f_off + t) & 3);  // floats of the row's start past a 16-byte boundary (W % 4 == 1)
+        const int a = (int)((stack_sign * (f_off + t)) & 3);  // floats of the row's start past a 16-byte boundary ((f_off + t) W mod 4)
         float* const orow = out_u + (int64_t)t * W;
         const bool interior = t >= hN && t + hN <= nframes - 1;  // no window index of this row is clamped
         // The chunks across block boundaries first: lane j puts together the one that ends with the
@@ -890,8 +1016,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         // a wave keeps several stores in flight.  Two copies of the loop -- rows whose window is not
         // clamped (aligned 16-byte reads, no index clamps) and rows near the utterance's ends -- so
         // that no branch sits between the reads (a branch makes the compiler wait for each one).
-        auto write_chunks = [&](auto interior_tag) {
+        auto write_chunks = [&](auto interior_tag, auto half_tag) {
           constexpr bool kInterior = decltype(interior_tag)::value;
+          constexpr bool kHalf = decltype(half_tag)::value;
           constexpr int U = 4;
           for (int ch0 = 0; ch0 <= ch_hi; ch0 += 64 * U) {
             f32x4_t v[U];
@@ -910,9 +1037,14 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #ifdef MFCC_ABL_ROWSRC
               v[u] = f32x4_t{(float)f, jv[0], (float)c, 0.f};
 #else
-              if (kInterior) {  // unclamped: frame t + f - h, whose phase is the block's, (a + f) mod 4
-                const float* const src = sring + ((t + f - hN - s_lo) & (kSRingRows - 1)) * kSRingPitch + ((a + f) & 3) + cr;
-                v[u] = *(const f32x4_t*)__builtin_assume_aligned(src, 16);
+              if (kInterior) {  // unclamped: frame t + f - h; c + its phase is congruent to c + a + f (+ 2 t when N % 4 == 3) mod 4
+                const float* const src = ring_row(t + f - hN) + cr;
+                if (kHalf) {
+                  const float2 lo2 = *(const float2*)__builtin_assume_aligned(src, 8), hi2 = *(const float2*)__builtin_assume_aligned(src + 2, 8);
+                  v[u] = f32x4_t{lo2.x, lo2.y, hi2.x, hi2.y};
+                } else {
+                  v[u] = *(const f32x4_t*)__builtin_assume_aligned(src, 16);
+                }
               } else {
                 const float* const src = ring_row(min(max(t + f - hN, 0), nframes - 1)) + cr;
                 v[u] = f32x4_t{src[0], src[1], src[2], src[3]};
@@ -948,10 +1080,14 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           }
         };
         // a first row (t == 0) is never interior except for a window of one frame, which the clamped copy handles too
-        if (interior && t > 0) write_chunks(std::true_type{});
-        else write_chunks(std::false_type{});
+        if (interior && t > 0) {
+          if (half_aligned) write_chunks(std::true_type{}, std::true_type{});
+          else write_chunks(std::true_type{}, std::false_type{});
+        } else {
+          write_chunks(std::false_type{}, std::false_type{});
+        }
         if (t == nframes - 1) {  // last row of the utterance: nobody follows to complete its last chunk
-          const int ntail = (a + 1) & 3;
+          const int ntail = (a + (int)W) & 3;
           if (lane < ntail) orow[W - ntail + lane] = ring_row(nframes - 1)[B - ntail + lane];
         }
       }
@@ -976,81 +1112,92 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the matrix-core chain
 #endif
     {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-      // k-step s of lane group g4 takes bin mel_k0 + 16 (s / 4) + 4 g4 + (s % 4): four consecutive
-      // steps of a lane are 16 contiguous bytes (one ds_read_b128); the plan lays the weights out
-      // in the same order
-      const float* Prow = xbuf + q * 512 + row_skew(q) + 4 * g4 + mel_k0;
+      // Lane 16 a + 4 b + c: block 4 a + b of the matrix instruction, column c.  As B operand it brings the
+      // spectrum of frame slot 4 a + c at the bin of block b; as A operand the weight of the group's filter c
+      // at that bin; its four result registers are filters 0..3 of the group for frame slot 4 a + c, summed
+      // over the bins block b walked.
+      const int frm = (lane >> 4) * 4 + (lane & 3);
+      const int blk = (lane >> 2) & 3;
+      const float* Prow = xbuf + frm * 512 + row_skew(frm) + 4 * blk;
+      const float* const dct_lane = dctl + 4 * (lane & 15);
+      f32x4 pd = {0.f, 0.f, 0.f, 0.f};  // this wave's share of the frame's cepstra: coefficients 4 blk .. 4 blk + 3
 #ifndef MFCC_ABL_MEL
-      // All kMelSteps k-steps run unconditionally (no branch between them, so the operand reads
-      // are issued ahead of the chain); steps a wave does not need carry zero weights, and the
-      // plan keeps kstart + 4*kMelSteps inside the zero-padded row.  Two accumulators: the MFMA
-      // dependency chain is half as long.
-      float pa[kMelSteps];
+      // All spectrum reads first (no branch between them, so they are issued ahead of the chain); a slot
+      // the wave does not use reads bin 0.. with zero weights and is skipped below.
+      f32x4 pa[kMelQuads];
 #pragma unroll
-      for (int s = 0; s < kMelSteps; s += 4) {
-        const float4 v = *(const float4*)__builtin_assume_aligned(Prow + 4 * s, 16);
-        pa[s] = v.x; pa[s + 1] = v.y; pa[s + 2] = v.z; pa[s + 3] = v.w;
+      for (int s = 0; s < kMelQuads; ++s) {
+        const float4 v = *(const float4*)__builtin_assume_aligned(Prow + 4 * (slot_info[s] & 63), 16);
+        pa[s] = f32x4{v.x, v.y, v.z, v.w};
       }
-      // The product is formed transposed, D[filter slot][frame] (weights as the A operand): a lane
-      // then holds filter slots g4 + 4 r of frame q, which is exactly the B-operand layout of a
-      // following product that sums over the filter slots -- the DCT needs no trip through LDS.
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, dwc = {0.f, 0.f, 0.f, 0.f};
+      // (the slot words pass through an empty asm statement so that the scalar tests on them are made here:
+      // hoisted out of the batch loop they would occupy some fifty scalar registers, more than there are)
+      int nslots_now = mel_nslots;
+      asm volatile("" : "+s"(nslots_now));
 #pragma unroll
-      for (int s = 0; s < kMelSteps - 8; s += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], pa[s], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s + 1], pa[s + 1], acc2, 0, 0, 0);
-      }
-      // the last two groups of four k-steps only where this wave's bin range reaches them (the
-      // matrix instructions share the vector ALU's issue time: a k-step of zero weights is not free)
+      for (int s = 0; s < kMelQuads; ++s) {
+        if (s >= nslots_now) break;  // wave-uniform
+        unsigned info = slot_info[s];
+        asm volatile("" : "+s"(info));
+        if (info & kSlotFirst) {
+          acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+          dwc = *(const f32x4*)__builtin_assume_aligned(dct_lane + 64 * ((info >> 17) & 15), 16);
+        }
+        // two accumulators: the dependency chain of the matrix instructions is half as long
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][0], pa[s][0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][1], pa[s][1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][2], pa[s][2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][3], pa[s][3], acc2, 0, 0, 0);
+        if (info & kSlotLast) {
+          // the group's sums: the four blocks of a row each walked a quarter of the bins
+          f32x4 mv = acc + acc2;
 #pragma unroll
-      for (int grp = kMelSteps / 4 - 2; grp < kMelSteps / 4; ++grp)
-        if (mel_groups > grp) {
+          for (int r = 0; r < 4; ++r) {
+            mv[r] += row_ror<4>(mv[r]);
+            mv[r] += row_ror<8>(mv[r]);
+          }
+          const int nf = (info >> 8) & 7, ff = (info >> 11) & 63;
+          if (floor_mel) {
+            // a real branch on the wave-uniform flag (written as a select, the compare and the select
+            // would run in the unfloored default too)
+            asm volatile("" ::: "memory");
 #pragma unroll
-          for (int s = 4 * grp; s < 4 * grp + 4; s += 2) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], pa[s], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s + 1], pa[s + 1], acc2, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) mv[r] = mv[r] == 0.f ? kEps64 : mv[r];
+          }
+          // ln at once (mfcc-self5.py:125-127, unfloored by default: ln 0 = -inf); the chained DCT takes
+          // log2 (its weights carry the factor ln 2); filters beyond the bank's last count as 0
+          float lm[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lm[r] = OUT == kOutLogmel ? fast_ln(mv[r]) : __builtin_amdgcn_logf(mv[r]);
+          if (nf < 4) {  // only a bank's last group, or a group cut in two, is short: a real branch, not four selects per group
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 1; r < 4; ++r) lm[r] = r < nf ? lm[r] : 0.f;
+          }
+          if (OUT == kOutLogmel) {
+            const int t = tb + frm;
+            if (blk == 0 && t < s_hi) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (r < nf) out_t0[(t - t0) * ld + ff + r] = lm[r];
+            }
+          } else {
+            // this group's part of the DCT-II * lifter product (mfcc-self5.py:136-156), same instruction:
+            // block 4 a + b now forms coefficients 4 b .. 4 b + 3 of frames 4 a .. 4 a + 3, one k-step per filter
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pd = __builtin_amdgcn_mfma_f32_4x4x1f32(dwc[r], lm[r], pd, 0, 0, 0);
           }
         }
-      acc += acc2;
+      }
 #else
-      acc[0] = Prow[0]; acc[1] = Prow[16]; acc[2] = bv[0]; acc[3] = bv[1];
+      pd[0] = Prow[0]; pd[1] = Prow[16]; pd[2] = bv[0][0]; pd[3] = bv[1][1];
 #endif
-      // slots below mel_nf are this wave's filters: ln at once (mfcc-self5.py:125-127, unfloored by
-      // default: ln 0 = -inf); slot 15 is this wave's share of the frame's energy sum
-      float lm[4];
-      f32x4 mv = acc;  // acc[3] of lane group 3 stays the unfloored energy partial
-      if (floor_mel) {
-        // a real branch on the wave-uniform flag (written as a select, the compare and the select
-        // would run in the unfloored default too)
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mv[r] = mv[r] == 0.f ? kEps64 : mv[r];
-      }
-      // ln for the ln-mel output; the chained DCT takes log2 (its weights carry the factor ln 2)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lm[r] = g4 + 4 * r < mel_nf ? (OUT == kOutLogmel ? fast_ln(mv[r]) : __builtin_amdgcn_logf(mv[r])) : 0.f;
-      if (g4 == 3) xbuf[q * kSlot + kPartEnergy + wave] = acc[3];
-      if (OUT == kOutLogmel) {
-        const int t = tb + q;
-        if (t < s_hi) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (g4 + 4 * r < mel_nf) out_t0[(t - t0) * ld + mel_ff + g4 + 4 * r] = lm[r];
-        }
-      } else {
-        // this wave's share of the DCT-II * lifter product (mfcc-self5.py:136-156): coefficient rows
-        // 4 g4 + r of frame q, summed over the wave's filters; the four shares meet in LDS.  k-step r
-        // takes the wave's filters 4 r .. 4 r + 3 (one per lane group), so a wave with few filters
-        // runs few steps
-        f32x4 pd = __builtin_amdgcn_mfma_f32_16x16x4f32(dw[0], lm[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-        for (int r = 1; r < 4; ++r)
-          if (4 * r < mel_nf) pd = __builtin_amdgcn_mfma_f32_16x16x4f32(dw[r], lm[r], pd, 0, 0, 0);
-        *(f32x4*)__builtin_assume_aligned(xbuf + part_index(q, wave, 4 * g4), 16) = pd;
-      }
+      if (OUT != kOutLogmel) *(f32x4*)__builtin_assume_aligned(xbuf + part_index(frm, wave, 4 * blk), 16) = pd;
     }
     // rows of the batch before last whose +-4-row context is now complete leave as whole output rows
-    if (OUT == kOutMfcc39 && tb > s_lo) emit_rows(tb - kBatch - kHalo);
+    if (kRows39 && tb > s_lo) emit_rows(tb - kBatch - kHalo);
     MFCC_STAMP(tb3);
 #ifndef MFCC_ABL_STAGE
     if (more) delta = stage_st(tb + kBatch);
@@ -1060,10 +1207,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     MFCC_STAMP(tb5);
     __builtin_amdgcn_s_setprio(MFCC_PRIO_P3);
 
-    // energy partials of frame slot i: spare slot of coefficient block i / 4 in every wave's tile
+    // energy of frame slot i: the sum its transform left (4|X|^2 or 2|X| per bin), scaled like the filter weights
     auto energy_of = [&](int i) {
-      const float* const ee = xbuf + i * kSlot + kPartEnergy;
-      float e = (ee[0] + ee[1]) + (ee[2] + ee[3]);
+      float e = xbuf[i * kSlot + kPartEnergy] * spec_scale;
       if (e == 0.f) e = kEps64;  // mfcc-self5.py:130-132
       return fast_ln(e);
     };
@@ -1082,7 +1228,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       const float e = energy_of(i);
       if (q == 0) v = e;
       if (q < ncep && t < s_hi) {
-        if (OUT == kOutMfcc39) {
+        if (kRows39) {
           const int rho = (t - s_lo + 8) & 31;
           ring[rho * RP + q] = v;
           if (kMirror && rho < 8) ring[(rho + 32) * RP + q] = v;
@@ -1091,6 +1237,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         }
       }
     }
+    // stacked MFCC-39: the rows below tb - 4 went into the ring of finished rows before the barrier above
+    if (OUT == kOutMfcc39Stack && tb > s_lo) write_stack_rows(tb - kHalo);
 #ifdef MFCC_DIAG
     {
       MFCC_STAMP(tb6);
@@ -1120,12 +1268,16 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       if (c < ncep) stream_emit_one(S0 + c, sa.e0 + i, sa.lo, sa.hi, ncep, c, ob + (int64_t)i * sa.out_ld);
     }
   }
-  if (OUT == kOutMfcc39) {
+  if (kRows39) {
     // the rows still held back: from 4 rows before the last batch to the tile's end (at most 20)
     __syncthreads();
     const int tb_last = s_lo + ((s_hi - s_lo - 1) / kBatch) * kBatch;
     emit_rows(tb_last - kHalo);
-    if (tb_last + kBatch - kHalo < t0 + nt) emit_rows(tb_last + kBatch - kHalo);
+    if (tb_last + kBatch - kHalo < (OUT == kOutMfcc39Stack ? o_hi : t0 + nt)) emit_rows(tb_last + kBatch - kHalo);
+    if (OUT == kOutMfcc39Stack) {
+      __syncthreads();
+      write_stack_rows(o_hi);  // every row this tile's windows reach is in the ring now
+    }
   }
 #ifdef MFCC_DIAG
   {

@@ -160,8 +160,8 @@ struct mfcc_plan {
   float* tw512 = nullptr;
   mfcc::PlanConst pc_host;
   mfcc::PlanConst* pc = nullptr;
-  float* melB = nullptr;
-  float* dctA = nullptr;
+  float* melW = nullptr;
+  float* dctW = nullptr;
   float* window = nullptr;
   float pre_hi, pre_lo, spec_scale;
   // general kernel (general_kernel.h): set when the configuration is outside the specialised kernel
@@ -222,13 +222,13 @@ extern "C" void mfcc_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p;
 #endif
 
 // launch_fused selectors of the stacked spectrum kinds (not part of the public out_kind values)
-enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101, kLaunchStream = 102 };
+enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101, kLaunchStream = 102, kLaunchMfcc39Stack = 103 };
 
 // The stacked-spectrum kernels use more dynamic LDS than a kernel may have without asking.  Asked once
 // per device, at plan creation (with that device current), so that a launch is nothing but a launch
 // (it may sit inside a stream capture).
 static int allow_stacked_lds() {
-  const int bytes = (int)(mfcc::smem_floats_stacked() * sizeof(float)) + MFCC_EXTRA_SMEM;
+  const int bytes = (int)(mfcc::smem_floats_stacked(mfcc::kStackMaxN) * sizeof(float)) + MFCC_EXTRA_SMEM;
 #define MFCC_ALLOW(OUT, T, G) \
   HIP_TRY(hipFuncSetAttribute((const void*)mfcc::fused_kernel<OUT, 0, T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
   MFCC_ALLOW(mfcc::kOutSpecStack, int16_t, mfcc::Geom16k);
@@ -240,6 +240,19 @@ static int allow_stacked_lds() {
   MFCC_ALLOW(mfcc::kOutLogspecStack, int16_t, mfcc::Geom8k);
   MFCC_ALLOW(mfcc::kOutLogspecStack, float, mfcc::Geom8k);
 #undef MFCC_ALLOW
+  // the stacked MFCC-39 kernels: statics ring + ring of finished rows
+  const int bytes39 = (int)((mfcc::smem_floats(mfcc::kMaxCep) + mfcc::oring_floats(mfcc::kMaxCep)) * sizeof(float)) + MFCC_EXTRA_SMEM;
+#define MFCC_ALLOW39(NCEP, T, G) \
+  HIP_TRY(hipFuncSetAttribute((const void*)mfcc::fused_kernel<mfcc::kOutMfcc39Stack, NCEP, T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes39))
+  MFCC_ALLOW39(13, int16_t, mfcc::Geom16k);
+  MFCC_ALLOW39(13, float, mfcc::Geom16k);
+  MFCC_ALLOW39(13, int16_t, mfcc::Geom8k);
+  MFCC_ALLOW39(13, float, mfcc::Geom8k);
+  MFCC_ALLOW39(0, int16_t, mfcc::Geom16k);
+  MFCC_ALLOW39(0, float, mfcc::Geom16k);
+  MFCC_ALLOW39(0, int16_t, mfcc::Geom8k);
+  MFCC_ALLOW39(0, float, mfcc::Geom8k);
+#undef MFCC_ALLOW39
   return MFCC_OK;
 }
 
@@ -262,9 +275,12 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
   }
   const bool c13 = plan->cfg.numcep == 13;
   // only the MFCC-39 kind keeps a ring of static rows in LDS: 13 floats per row where numcep is a compile-time 13
-  const int ring_pitch = out_kind == MFCC_OUT_MFCC39 ? (c13 ? 13 : mfcc::kMaxCep) : 0;
+  const bool rows39 = out_kind == MFCC_OUT_MFCC39 || out_kind == kLaunchMfcc39Stack;
+  const int ring_pitch = rows39 ? (c13 ? 13 : mfcc::kMaxCep) : 0;
   const bool stacked = out_kind == kLaunchSpecStack || out_kind == kLaunchLogspecStack;
-  const size_t smem = (stacked ? mfcc::smem_floats_stacked() : mfcc::smem_floats(ring_pitch)) * sizeof(float) + MFCC_EXTRA_SMEM;
+  const size_t smem = (stacked ? mfcc::smem_floats_stacked(fp.stack_n)
+                               : mfcc::smem_floats(ring_pitch) + (out_kind == kLaunchMfcc39Stack ? mfcc::oring_floats(plan->cfg.numcep) : 0)) *
+                          sizeof(float) + MFCC_EXTRA_SMEM;
   const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
   // (the stacked kinds take more than the 64 KiB of dynamic LDS a kernel gets without asking: allow_stacked_lds())
 #define MFCC_LAUNCH_G(OUT, NCEP, G)                                                                          \
@@ -294,6 +310,10 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     case kLaunchStream:
       if (c13) MFCC_LAUNCH(mfcc::kOutStream, 13);
       else MFCC_LAUNCH(mfcc::kOutStream, 0);
+      break;
+    case kLaunchMfcc39Stack:
+      if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39Stack, 13);
+      else MFCC_LAUNCH(mfcc::kOutMfcc39Stack, 0);
       break;
   }
 #undef MFCC_LAUNCH_G
@@ -366,7 +386,8 @@ int64_t mfcc_frames_for_length(int64_t n_samples, int32_t frame_size, int32_t fr
 }
 
 // Tables of the specialised kernel.  Returns 1 (and leaves the plan without them) when the
-// filterbank does not fit that kernel's fixed number of matrix-core k-steps per wave.
+// filterbank does not fit that kernel's slots of matrix-core k-steps per wave (a bank of few, very
+// wide filters: a group of four then covers more bins than a wave walks).
 static int build_specialised(mfcc_plan* p) {
   const mfcc_config* const cfg = &p->cfg;
   const int32_t nfft = p->nfft, size = p->frame_size;
@@ -384,100 +405,96 @@ static int build_specialised(mfcc_plan* p) {
     for (int m = 0; m < nmel; ++m)
       for (int k = 0; k < nb; ++k) bank[(size_t)m * mfcc::kNbin + (size_t)k * decim] = own[(size_t)m * nb + k];
   }
-  std::vector<int> first(nmel, mfcc::kNbin), last(nmel, -1);
-  for (int m = 0; m < nmel; ++m)
-    for (int k = 0; k < mfcc::kNbin; ++k)
-      if (bank[(size_t)m * mfcc::kNbin + k] != 0.0) {
-        first[m] = std::min(first[m], k);
-        last[m] = std::max(last[m], k);
-      }
-  // Split the filters into 4 contiguous column groups (one per wave, <= 15 each, may be empty)
-  // so that the longest bin range any wave has to walk is shortest.  Every bin also adds to
-  // the energy column of exactly one wave: group g takes bins [estart[g], estart[g+1]).
-  int best_cut[5] = {0, 0, 0, 0, nmel}, best_max = 1 << 30, best_sum = 1 << 30;
-  int best_k0[4] = {0, 0, 0, 0}, best_es[5] = {0, 0, 0, 0, mfcc::kNbin}, best_steps[4] = {0, 0, 0, 0};
-  for (int c1 = 0; c1 <= nmel; ++c1)
-    for (int c2 = c1; c2 <= nmel; ++c2)
-      for (int c3 = c2; c3 <= nmel; ++c3) {
-        const int cut[5] = {0, c1, c2, c3, nmel};
-        bool ok = true;
-        int fb[4], lb[4];
-        for (int g = 0; g < 4 && ok; ++g) {
-          if (cut[g + 1] - cut[g] > mfcc::kMelCols) ok = false;
-          fb[g] = mfcc::kNbin;
-          lb[g] = -1;
-          for (int m = cut[g]; m < cut[g + 1]; ++m) { fb[g] = std::min(fb[g], first[m]); lb[g] = std::max(lb[g], last[m]); }
-        }
-        if (!ok) continue;
-        int es[5];
-        es[0] = 0;
-        for (int g = 1; g < 4; ++g) es[g] = std::max(es[g - 1], std::min(fb[g], mfcc::kNbin));
-        es[4] = mfcc::kNbin;
-        // Cost of a wave in matrix instructions (they share the vector ALU's issue time, so every
-        // one counts): its filterbank k-steps, run in groups of four (16 bins), plus the k-steps
-        // of its share of the DCT product, one per four filters.
-        int mx = 0, sum = 0, k0[4], st[4];
-        bool fits = true;
-        for (int g = 0; g < 4; ++g) {
-          // a wave's bin range starts at a multiple of 4 (its spectrum reads are 16-byte aligned)
-          // and early enough for all kMelSteps steps to stay inside the zero-padded row
-          int lo = std::min(es[g], fb[g]) & ~3;
-          const int hi = std::max(lb[g] + 1, es[g + 1]);
-          lo = std::min(std::min(lo, hi) & ~3, mfcc::kRowPad - 4 * mfcc::kMelSteps);
-          k0[g] = lo;
-          st[g] = hi > lo ? (hi - lo + 3) / 4 : 0;
-          if (st[g] > mfcc::kMelSteps) fits = false;
-          const int cost = (st[g] + 3) / 4 * 4 + std::max(1, (cut[g + 1] - cut[g] + 3) / 4);
-          mx = std::max(mx, cost);
-          sum += cost;
-        }
-        if (!fits) continue;
-        if (mx < best_max || (mx == best_max && sum < best_sum)) {
-          best_max = mx; best_sum = sum;
-          for (int g = 0; g < 5; ++g) { best_cut[g] = cut[g]; best_es[g] = es[g]; }
-          for (int g = 0; g < 4; ++g) { best_k0[g] = k0[g]; best_steps[g] = st[g]; }
-        }
-      }
-  if (best_max == 1 << 30) return 1;  // no split fits the specialised kernel's k-step budget
+  // Groups of up to four consecutive filters; each walks the bins that carry a weight of one of its filters,
+  // from a multiple of four on, in quads of 16 bins that end inside the zero-padded spectrum row.
+  struct Group { int first, nfilt, k0, quads; };
+  auto measure = [&](Group& gr) {
+    int lo = mfcc::kNbin, hi = 0;
+    for (int m = gr.first; m < gr.first + gr.nfilt; ++m)
+      for (int k = 0; k < mfcc::kNbin; ++k)
+        if (bank[(size_t)m * mfcc::kNbin + k] != 0.0) { lo = std::min(lo, k); hi = std::max(hi, k + 1); }
+    if (hi <= lo) { lo = 0; hi = 1; }  // a group without any weight (degenerate bank) still yields ln 0 for its filters
+    gr.k0 = lo & ~3;
+    gr.quads = (hi - gr.k0 + 15) / 16;
+    if (gr.k0 + 16 * gr.quads > mfcc::kRowPad) gr.k0 = mfcc::kRowPad - 16 * gr.quads;
+    static_assert(mfcc::kRowPad % 4 == 0, "clamped start stays 16-byte aligned");
+  };
+  std::vector<Group> groups;
+  for (int f = 0; f < nmel; f += 4) {
+    groups.push_back(Group{f, std::min(4, nmel - f), 0, 0});
+    measure(groups.back());
+  }
+  // Longest group first onto the wave with the least work so far (cost in matrix instructions: four per
+  // quad, four for the group's part of the DCT product); a wave takes at most kMelQuads quads.  While that
+  // fails (few, wide filters), the widest group that still has two filters is cut in two.
+  std::vector<Group> mine[4];
+  for (;;) {
+    std::vector<Group> order = groups;
+    std::stable_sort(order.begin(), order.end(), [](const Group& x, const Group& y) { return x.quads > y.quads; });
+    int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+    for (int w = 0; w < 4; ++w) mine[w].clear();
+    bool ok = (int)groups.size() <= mfcc::kMelGroups;
+    for (size_t i = 0; i < order.size() && ok; ++i) {
+      const Group& gr = order[i];
+      int best = -1;
+      for (int w = 0; w < 4; ++w)
+        if (used[w] + gr.quads <= mfcc::kMelQuads && (best < 0 || load[w] < load[best])) best = w;
+      if (best < 0) { ok = false; break; }
+      mine[best].push_back(gr);
+      load[best] += 4 * gr.quads + 4;
+      used[best] += gr.quads;
+    }
+    if (ok) break;
+    int widest = -1;
+    for (size_t i = 0; i < groups.size(); ++i)
+      if (groups[i].nfilt > 1 && (widest < 0 || groups[i].quads > groups[(size_t)widest].quads)) widest = (int)i;
+    if (widest < 0 || (int)groups.size() >= mfcc::kMelGroups) return 1;  // the bank does not fit the specialised kernel's slots
+    Group lo_half = groups[(size_t)widest], hi_half = lo_half;
+    lo_half.nfilt = (lo_half.nfilt + 1) / 2;
+    hi_half.first += lo_half.nfilt;
+    hi_half.nfilt -= lo_half.nfilt;
+    measure(lo_half);
+    measure(hi_half);
+    groups[(size_t)widest] = lo_half;
+    groups.insert(groups.begin() + widest + 1, hi_half);
+  }
+  const int ngroups = (int)groups.size();
+  auto group_number = [&](const Group& gr) {
+    for (int g = 0; g < ngroups; ++g)
+      if (groups[(size_t)g].first == gr.first) return g;
+    return 0;
+  };
   mfcc::PlanConst& pch = p->pc_host;
   memset(&pch, 0, sizeof(pch));
   mfcc::MelMap& pmap = pch.map;
-  std::vector<float> melB((size_t)4 * mfcc::kMelSteps * 64, 0.f);
-  for (int g = 0; g < 4; ++g) {
-    // every wave runs all kMelSteps k-steps: keep them inside the zero-padded spectrum row
-    pmap.kstart[g] = std::min(best_k0[g] & ~3, mfcc::kRowPad - 4 * mfcc::kMelSteps);
-    static_assert((mfcc::kRowPad - 4 * mfcc::kMelSteps) % 4 == 0, "clamped start stays 16-byte aligned");
-    pmap.first_filter[g] = best_cut[g];
-    pmap.nfilt[g] = best_cut[g + 1] - best_cut[g];
-    pch.mel_steps[g] = 0;  // set below: one past the last k-step that carries a weight
-    for (int sidx = 0; sidx < mfcc::kMelSteps; ++sidx)
-      for (int lane = 0; lane < 64; ++lane) {
-        // k-step sidx of lane group (lane >> 4) takes bin kstart + 16 (sidx / 4) + 4 (lane >> 4) + sidx % 4
-        // row m = lane & 15 of the product lands in register m % 4 of lane group m / 4: give it the
-        // wave's filter m / 4 + 4 (m % 4), so that register r of the four lane groups holds filters
-        // 4 r .. 4 r + 3 and the chained DCT product needs only ceil(nfilt / 4) k-steps (row 15 maps to itself)
-        const int k = pmap.kstart[g] + 16 * (sidx / 4) + 4 * (lane >> 4) + sidx % 4, m = lane & 15, j = (m >> 2) + 4 * (m & 3);
-        double w = 0.0;
-        if (k < mfcc::kNbin) {
-          if (j < pmap.nfilt[g]) w = bank[(size_t)(best_cut[g] + j) * mfcc::kNbin + k];
-          else if (j == mfcc::kMelCols && k >= best_es[g] && k < best_es[g + 1] && k % decim == 0) w = 1.0;
-        }
-        // four consecutive k-steps of a lane are 16 contiguous bytes: [wave][step/4][lane][step%4]
-        melB[(((size_t)g * (mfcc::kMelSteps / 4) + sidx / 4) * 64 + lane) * 4 + sidx % 4] = (float)(w * (double)p->spec_scale);
-        if (w != 0.0) pch.mel_steps[g] = std::max(pch.mel_steps[g], sidx + 1);
+  std::vector<float> melW((size_t)4 * mfcc::kMelQuads * 16 * 4, 0.f);
+  for (int w = 0; w < 4; ++w) {
+    int slot = 0;
+    for (const Group& gr : mine[w])
+      for (int i = 0; i < gr.quads; ++i, ++slot) {
+        const int bin0 = gr.k0 + 16 * i;
+        pmap.slot[w][slot] = (uint32_t)(bin0 / 4) | (i == 0 ? mfcc::kSlotFirst : 0u) | (i == gr.quads - 1 ? mfcc::kSlotLast : 0u) |
+                             ((uint32_t)gr.nfilt << 8) | ((uint32_t)gr.first << 11) | ((uint32_t)group_number(gr) << 17);
+        for (int b = 0; b < 4; ++b)
+          for (int f = 0; f < gr.nfilt; ++f)
+            for (int st = 0; st < 4; ++st) {
+              const int k = bin0 + 4 * b + st;
+              const double wgt = k < mfcc::kNbin ? bank[(size_t)(gr.first + f) * mfcc::kNbin + k] : 0.0;
+              melW[(((size_t)w * mfcc::kMelQuads + slot) * 16 + 4 * b + f) * 4 + st] = (float)(wgt * (double)p->spec_scale);
+            }
       }
+    pmap.nslots[w] = slot;
   }
-  pmap.ndct = (nmel + 3) / 4;
   const std::vector<double> dl = mfcc::dct_lifter(nmel, cfg->numcep, cfg->lift_factor, true);
-  // per-wave weights of the chained product (see PlanConst::dctA)
-  std::vector<float> dctA((size_t)4 * 64 * 4, 0.f);
-  for (int g = 0; g < 4; ++g)
-    for (int lane = 0; lane < 64; ++lane)
-      for (int r = 0; r < 4; ++r) {
-        const int c = lane & 15, j = (lane >> 4) + 4 * r;
-        if (j < pmap.nfilt[g] && c < cfg->numcep)
-          dctA[((size_t)g * 64 + lane) * 4 + r] = (float)(dl[(size_t)(pmap.first_filter[g] + j) * cfg->numcep + c] * M_LN2);  // the kernel hands over log2 of the mel sums
-      }
+  // weights of the chained product (see PlanConst::dctW); the kernel hands over log2 of the mel sums
+  std::vector<float> dctW((size_t)mfcc::kMelGroups * 64, 0.f);
+  for (int g = 0; g < ngroups; ++g)
+    for (int b = 0; b < 4; ++b)
+      for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < groups[(size_t)g].nfilt; ++r) {
+          const int c = 4 * b + i, m = groups[(size_t)g].first + r;
+          if (c < cfg->numcep && m < nmel) dctW[(size_t)g * 64 + (4 * b + i) * 4 + r] = (float)(dl[(size_t)m * cfg->numcep + c] * M_LN2);
+        }
   std::vector<float> win;
   if (cfg->window == MFCC_WINDOW_HAMMING) {
     const std::vector<double> h = mfcc::hamming(size);
@@ -486,12 +503,12 @@ static int build_specialised(mfcc_plan* p) {
   }
   int rc;
   if ((rc = upload(mfcc::twiddle512(), &p->tw512)) ||
-      (rc = upload(melB, &p->melB)) || (rc = upload(dctA, &p->dctA)) || (rc = upload(win, &p->window))) {
+      (rc = upload(melW, &p->melW)) || (rc = upload(dctW, &p->dctW)) || (rc = upload(win, &p->window))) {
     return rc;
   }
   pch.tw512 = p->tw512;
-  pch.melB = p->melB;
-  pch.dctA = p->dctA;
+  pch.melW = p->melW;
+  pch.dctW = p->dctW;
   pch.window = p->window;
   pch.nmel = nmel;
   pch.numcep = cfg->numcep;
@@ -682,8 +699,8 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
 int mfcc_plan_destroy(mfcc_plan* p) {
   if (!p) return MFCC_OK;
   (void)hipFree(p->tw512);
-  (void)hipFree(p->melB);
-  (void)hipFree(p->dctA);
+  (void)hipFree(p->melW);
+  (void)hipFree(p->dctW);
   (void)hipFree(p->window);
   (void)hipFree(p->pc);
   (void)hipFree(p->gc);
@@ -947,7 +964,7 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
   if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: null plan or layout");
   if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
   if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: the layout holds frame counts only (mfcc_layout_create_frames)");
-  if (plan->general || plan->nfft != mfcc::kNfft)
+  if (plan->general || (plan->nfft != mfcc::kNfft && out_kind != MFCC_OUT_MFCC39))
     return fail(MFCC_ERR_UNSUPPORTED, "mfcc_forward_stacked: built for 512-point plans of the specialised kernel (this one: framing %d/%d, "
                 "%d-point FFT%s); use mfcc_forward + mfcc_stack_context", plan->frame_size, plan->frame_step, plan->nfft,
                 plan->general ? ", general kernel" : "");
@@ -956,13 +973,15 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
     if (rc_l) return rc_l;
   }
   if (audio_dtype != MFCC_AUDIO_I16 && audio_dtype != MFCC_AUDIO_F32) return fail(MFCC_ERR_INVALID, "audio_dtype=%d", audio_dtype);
-  if (out_kind != MFCC_OUT_SPEC && out_kind != MFCC_OUT_LOGSPEC)
-    return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: out_kind must be MFCC_OUT_SPEC or MFCC_OUT_LOGSPEC");
+  if (out_kind != MFCC_OUT_SPEC && out_kind != MFCC_OUT_LOGSPEC && out_kind != MFCC_OUT_MFCC39)
+    return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: out_kind must be MFCC_OUT_SPEC, MFCC_OUT_LOGSPEC or MFCC_OUT_MFCC39");
+  if (out_kind == MFCC_OUT_MFCC39 && framenum < 3)
+    return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: MFCC_OUT_MFCC39 takes framenum >= 3 (framenum 1 is mfcc_forward)");
   if (framenum < 1 || framenum % 2 == 0)
     return fail(MFCC_ERR_INVALID, "framenum=%d: use an odd number of frames (MLP_5hidlayer_40.py:261-262 warns the same)", framenum);
-  if (framenum % 4 != 1 || framenum > mfcc::kStackMaxN)
-    return fail(MFCC_ERR_UNSUPPORTED, "framenum=%d: the one-launch path takes framenum = 1, 5, 9, 13, 17 (rows keep one 16-byte "
-                "phase, and the window has to fit the ring of spectrum rows in LDS); use mfcc_forward + mfcc_stack_context", framenum);
+  if (framenum > mfcc::kStackMaxN)
+    return fail(MFCC_ERR_UNSUPPORTED, "framenum=%d: the one-launch path takes odd framenum up to %d (the window has to fit the ring of "
+                "spectrum rows in LDS); use mfcc_forward + mfcc_stack_context", framenum, mfcc::kStackMaxN);
   if (layout->n_utts == 0 || layout->n_tiles == 0) return MFCC_OK;
   if (!out || !audio) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: null device pointer");
   if ((uintptr_t)out & 15) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: out must be 16-byte aligned");
@@ -974,14 +993,15 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
   fp.frame_off = layout->d_frame_off;
   fp.tiles = layout->d_tiles;
   fp.out = out;
-  fp.out_ld = (int64_t)framenum * (plan->nfft / 2 + 1);
+  fp.out_ld = out_kind == MFCC_OUT_MFCC39 ? (int64_t)framenum * 3 * plan->cfg.numcep : (int64_t)framenum * (plan->nfft / 2 + 1);
   fp.total_elems = layout->total_samples;
   fp.pc = plan->pc;
   fp.stack_n = framenum;
 #ifdef MFCC_DIAG
   fp.dbg = nullptr;
 #endif
-  launch_fused(plan, fp, layout->n_tiles, out_kind == MFCC_OUT_SPEC ? kLaunchSpecStack : kLaunchLogspecStack,
+  launch_fused(plan, fp, layout->n_tiles,
+               out_kind == MFCC_OUT_MFCC39 ? kLaunchMfcc39Stack : (out_kind == MFCC_OUT_SPEC ? kLaunchSpecStack : kLaunchLogspecStack),
                audio_dtype == MFCC_AUDIO_I16, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return MFCC_OK;

@@ -365,8 +365,8 @@ def spectrum_stack(fe, audio, layout, framenum, out=None, log=True):
     """The "257 coefficients x N frames" input of the MLP/CNN scripts (MLP_5hidlayer_40.py:244-248)
     straight from audio: spectrum rows of ``fe`` (ln of them when ``log``) stacked over ``framenum``
     frames with edge replication per utterance -> float32 [sum F, framenum * (nfft/2+1)].  One launch
-    when framenum is 1, 5, 9, 13 or 17 (each 257-bin row is computed once and written framenum times); other odd
-    values go through ``forward`` + ``stack_context``."""
+    for odd framenum up to 21 (each 257-bin row is computed once and written framenum times); larger
+    windows go through ``forward`` + ``stack_context``."""
     if not audio.is_cuda or not audio.is_contiguous() or audio.dtype not in (torch.int16, torch.float32):
         raise ValueError("audio must be a contiguous int16 or float32 device tensor")
     if audio.numel() != layout.total_samples:
@@ -374,7 +374,7 @@ def spectrum_stack(fe, audio, layout, framenum, out=None, log=True):
     framenum = int(framenum)
     width = fe.plan.out_width("spec")
     shape = (layout.total_frames, framenum * width)
-    if framenum % 4 != 1 or framenum > 17 or fe.plan.general or fe.plan.num_fft != 512:
+    if framenum % 2 != 1 or framenum > 21 or fe.plan.general or fe.plan.num_fft != 512:
         spec = fe.forward(audio, layout, kind="logspec" if log else "spec")
         return stack_context(spec, framenum, frame_counts=np.diff(layout.frame_offsets), out=out)
     if out is None:
@@ -385,6 +385,33 @@ def spectrum_stack(fe, audio, layout, framenum, out=None, log=True):
     with _on(fe.plan.device, audio, out):
         capi.check(capi.load().mfcc_forward_stacked(fe.plan._h, layout._h, _ptr(audio), code, framenum, _ptr(out),
                                                     capi.OUT_LOGSPEC if log else capi.OUT_SPEC, _stream_ptr()))
+    return out
+
+
+def mfcc39_stack(fe, audio, layout, framenum, out=None):
+    """The "39 coefficients x N frames" input of the MLP scripts (coeffs = 39, e.g. framenum = 11,
+    MLP_5hidlayer_40.py:244-248) straight from audio: the MFCC-39 rows of ``fe`` stacked over ``framenum``
+    frames with edge replication per utterance (padUtterance + slidingWin, MLP_5hidlayer_40.py:70-105)
+    -> float32 [sum F, framenum * 3 * numcep].  One launch for odd framenum 3 .. 21 on the specialised
+    kernel (the rows never visit HBM on their own); otherwise ``forward`` + ``stack_context``."""
+    if not audio.is_cuda or not audio.is_contiguous() or audio.dtype not in (torch.int16, torch.float32):
+        raise ValueError("audio must be a contiguous int16 or float32 device tensor")
+    if audio.numel() != layout.total_samples:
+        raise ValueError(f"audio has {audio.numel()} samples, layout expects {layout.total_samples}")
+    framenum = int(framenum)
+    width = fe.plan.out_width("mfcc39")
+    shape = (layout.total_frames, framenum * width)
+    if framenum % 2 != 1 or framenum < 3 or framenum > 21 or fe.plan.general:
+        rows = fe.forward(audio, layout, kind="mfcc39")
+        return stack_context(rows, framenum, frame_counts=np.diff(layout.frame_offsets), out=out)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=audio.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.data_ptr() % 16:
+        raise ValueError(f"out must be a contiguous, 16-byte aligned float32 {shape} device tensor")
+    code = capi.AUDIO_I16 if audio.dtype == torch.int16 else capi.AUDIO_F32
+    with _on(fe.plan.device, audio, out):
+        capi.check(capi.load().mfcc_forward_stacked(fe.plan._h, layout._h, _ptr(audio), code, framenum, _ptr(out),
+                                                    capi.OUT_MFCC39, _stream_ptr()))
     return out
 
 

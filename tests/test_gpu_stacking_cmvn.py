@@ -247,13 +247,15 @@ def test_spectrum_stack_one_launch_equals_two_kernels(M, variant, log):
     spec = fe.forward(packed, lay, kind="logspec" if log else "spec")
     counts = np.diff(lay.frame_offsets)
     assert list(counts) == frames
-    for framenum in (17, 5, 1):
+    # every odd window up to 21 frames in one launch: rows of N * 257 floats start on every 16-byte phase when
+    # N % 4 == 1 and N % 4 == 3 alike (the second kind reads the ring on 8-byte boundaries); 19 and 21 use the longer ring
+    for framenum in (17, 5, 1, 7, 11, 15, 19, 21, 3, 9, 13):
         two = M.stack_context(spec, framenum, frame_counts=counts)
         one = M.spectrum_stack(fe, packed, lay, framenum, log=log)
         assert one.shape == (sum(frames), framenum * 257)
-        assert torch.equal(one, two)
-    # framenum % 4 == 3 takes the two-kernel route inside the same call
-    assert torch.equal(M.spectrum_stack(fe, packed, lay, 11, log=log), M.stack_context(spec, 11, frame_counts=counts))
+        assert torch.equal(one, two), framenum
+    # beyond 21 frames the same call takes the two-kernel route
+    assert torch.equal(M.spectrum_stack(fe, packed, lay, 23, log=log), M.stack_context(spec, 23, frame_counts=counts))
     # and the values are the reference's: spectrum of the oracle, stacked by the oracle
     u = 7                                                              # the 40-frame utterance
     ref = O.stack_context(O.spectrum257(audios[u], variant, log=log), 17)
@@ -264,6 +266,63 @@ def test_spectrum_stack_one_launch_equals_two_kernels(M, variant, log):
         assert (np.abs(got - ref) <= 2e-6 * np.abs(ref).max()).all()
     with pytest.raises(ValueError):
         M.spectrum_stack(fe, packed, lay, 17, out=torch.empty(3, 3, device="cuda"))
+
+
+@pytest.mark.parametrize("variant", ["self5", "self15"])
+def test_mfcc39_stack_one_launch_equals_two_kernels(M, variant):
+    """mfcc_forward_stacked(MFCC_OUT_MFCC39): the finished MFCC-39 rows stacked over N frames in one launch
+    (coeffs = 39, framenum = 11 of the reference's best model, MLP_5hidlayer_40.py:70-105,244-248) against
+    mfcc_forward + mfcc_stack_context bit for bit, on a ragged batch with one-frame, shorter-than-window,
+    tile-sized and multi-tile utterances, for every odd window 3 .. 21 (mfcc_stack_context itself is held to the
+    reference's 39-wide, 11-frame golden in test_stacking_bit_exact), and against the oracle's stacking of its own rows."""
+    rng = np.random.default_rng(34)
+    frames = [1, 2, 3, 8, 9, 16, 17, 40, 299, 304, 305, 700, 5, 296, 297, 24]
+    lengths = [400 + 160 * (f - 1) - int(rng.integers(0, 160)) if f > 1 else 123 for f in frames]
+    audios = [np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths]
+    fe = M.MFCC(variant)
+    lay = fe.layout(lengths)
+    packed = torch.from_numpy(np.concatenate(audios)).cuda()
+    rows = fe.forward(packed, lay)
+    counts = np.diff(lay.frame_offsets)
+    assert list(counts) == frames
+    for framenum in (11, 3, 5, 7, 9, 13, 15, 17, 19, 21):
+        two = M.stack_context(rows, framenum, frame_counts=counts)
+        one = M.mfcc39_stack(fe, packed, lay, framenum)
+        assert one.shape == (sum(frames), framenum * 39)
+        assert torch.equal(one, two), framenum
+    assert torch.equal(M.mfcc39_stack(fe, packed, lay, 23), M.stack_context(rows, 23, frame_counts=counts))   # two-kernel route
+    u = 7                                                              # the 40-frame utterance
+    ref = O.stack_context(O.mfcc39(audios[u], variant, loop=False), 11)
+    got = M.mfcc39_stack(fe, packed, lay, 11)[lay.frame_offsets[u]:lay.frame_offsets[u + 1]].cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-3
+    # float32 samples, another numcep (run-time row width 3 * 12 = 36), the 8 kHz framing
+    f32 = torch.from_numpy(np.concatenate(audios).astype(np.float32) / 32768).cuda()
+    assert torch.equal(M.mfcc39_stack(fe, f32, lay, 11), M.stack_context(fe.forward(f32, lay), 11, frame_counts=counts))
+    fe12 = M.MFCC(variant, numcep=12)
+    assert torch.equal(M.mfcc39_stack(fe12, packed, lay, 7), M.stack_context(fe12.forward(packed, lay), 7, frame_counts=counts))
+    fe8 = M.MFCC(variant, fs=8000)
+    assert not fe8.plan.general
+    l8 = [200 + 80 * (f - 1) - int(rng.integers(0, 80)) if f > 1 else 50 for f in frames]
+    a8 = torch.from_numpy(np.concatenate([np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in l8])).cuda()
+    lay8 = fe8.layout(l8)
+    assert torch.equal(M.mfcc39_stack(fe8, a8, lay8, 11), M.stack_context(fe8.forward(a8, lay8), 11, frame_counts=frames))
+    with pytest.raises(ValueError):
+        M.mfcc39_stack(fe, packed, lay, 11, out=torch.empty(3, 3, device="cuda"))
+
+
+def test_mfcc39_stack_full_batch(M):
+    """The bench batch (10 000 x 3 s) stacked over 11 frames in one launch: sampled utterances equal the
+    two-kernel route bit for bit (tiles cut short at the end of the grid included)."""
+    n_utt, n_len = 10000, 48000
+    audio = (torch.randn(n_utt * n_len // 8, device="cuda").repeat(8) * 3000).clamp(-32768, 32767).to(torch.int16)
+    fe = M.MFCC("self5")
+    lay = fe.layout([n_len] * n_utt)
+    got = M.mfcc39_stack(fe, audio, lay, 11)
+    rows = fe.forward(audio, lay)
+    for u in (0, 1, 4999, 9984, 9985, 9999):
+        want = M.stack_context(rows[u * 299:(u + 1) * 299].contiguous(), 11)
+        assert torch.equal(got[u * 299:(u + 1) * 299], want), u
+    del got, rows
 
 
 def test_spectrum_stack_other_instantiations(M):
@@ -281,7 +340,7 @@ def test_spectrum_stack_other_instantiations(M):
         lay = fe.layout(lengths)
         spec = fe.forward(samples, lay, kind="logspec")
         counts = np.diff(lay.frame_offsets)
-        for framenum in (9, 13, 17):
+        for framenum in (9, 11, 17, 21):
             assert torch.equal(M.spectrum_stack(fe, samples, lay, framenum), M.stack_context(spec, framenum, frame_counts=counts))
     # 25 ms / 10 ms at 8 kHz with the 512-point FFT of the CTC scripts: 200/80-sample frames on the specialised kernel
     fe8 = M.MFCC("self5", fs=8000, num_fft=512)
@@ -291,7 +350,8 @@ def test_spectrum_stack_other_instantiations(M):
     lay8 = fe8.layout(l8)
     assert list(np.diff(lay8.frame_offsets)) == frames
     spec8 = fe8.forward(a8, lay8, kind="spec")
-    assert torch.equal(M.spectrum_stack(fe8, a8, lay8, 17, log=False), M.stack_context(spec8, 17, frame_counts=frames))
+    for framenum in (17, 7):
+        assert torch.equal(M.spectrum_stack(fe8, a8, lay8, framenum, log=False), M.stack_context(spec8, framenum, frame_counts=frames))
     # 800 equal utterances: 32 tiles beyond one round of 3 x 256 workgroups are cut into short ones
     fe = M.MFCC("self15")
     n_utt, n_len = 800, 16000
