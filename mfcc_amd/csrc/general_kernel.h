@@ -7,7 +7,14 @@
 // Work decomposition
 //   grid       one workgroup (4 waves) per tile of consecutive output frames of one utterance
 //              (same Tile list as the specialised kernel, shorter tiles);
-//   wave       one frame at a time: the frame_size samples are read from global memory
+//   wave       FFT lengths up to 512 (general16_kernel): four frames at a time, 16 lanes per frame, on the
+//              register transform of fft_lane.h -- an nfft-point transform of a frame of at most nfft
+//              samples is every (512 / nfft)-th bin of the 512-point transform of the same zero-padded
+//              frame; the samples come straight from global memory, everything after the transform
+//              (filters, ln, DCT) runs on the frame's 16 lanes out of the wave's own LDS rows, so the
+//              waves of a workgroup never wait for each other until the tile's rows are complete.
+//              Longer FFTs (general_kernel):
+//              one frame at a time: the frame_size samples are read from global memory
 //              (pre-emphasised on the fly, zero beyond the utterance end), packed as nfft/2
 //              complex points z[n] = x[2n] + i x[2n+1] into the wave's own LDS buffer in
 //              bit-reversed order, transformed by radix-2 butterflies in LDS (a wave's LDS
@@ -51,6 +58,7 @@ struct GeneralConst {
   int32_t stat_rows;      // rows of the statics / delta arrays in LDS (>= tile frames + 4 * pad_fac)
   int32_t bankc_lds;      // > 0: floats of LDS that hold a copy of bankc (read from there)
   int32_t dct_lds;        // > 0: floats of LDS that hold a copy of dctl
+  int32_t lane16;         // 1: nfft <= 512, general16_kernel runs; tw then holds [512][2] exp(-2 pi i k / 512)
 };
 
 // dynamic LDS of the kernel, in floats: the twiddle table (nfft floats), the filter weights and
@@ -61,8 +69,18 @@ __host__ __device__ inline int general_row_floats(int nfft) { return (nfft / 2 +
 __host__ __device__ inline int general_wave_floats(int nfft, int nmel) {
   return nfft + general_row_floats(nfft) + ((nmel + 1 + 3) & ~3);
 }
+// general16_kernel: the 512-point twiddle table (1024 floats), the filters' band table (3 ints per filter),
+// per wave four 2 KiB exchange buffers (the frames' spectrum rows afterwards) and four ln-mel rows
+__host__ __device__ inline int general16_lrow_floats(int nmel) { return (nmel + 1 + 3) & ~3; }
+__host__ __device__ inline int general16_wave_floats(int nmel) { return 4 * 512 + 4 * general16_lrow_floats(nmel); }
+__host__ __device__ inline int general16_band_floats(int nmel) { return (3 * nmel + 3) & ~3; }
+// LDS floats of either kernel apart from the optional table copies and the static / delta rows
+inline size_t general_fixed_floats(int nfft, int nmel) {
+  return nfft <= 512 ? (size_t)1024 + general16_band_floats(nmel) + (size_t)4 * general16_wave_floats(nmel)
+                     : (size_t)nfft + (size_t)4 * general_wave_floats(nfft, nmel);
+}
 inline size_t general_smem_bytes(int nfft, int nmel, int numcep, int stat_rows) {
-  return ((size_t)nfft + (size_t)4 * general_wave_floats(nfft, nmel) + (size_t)2 * stat_rows * numcep) * sizeof(float);
+  return (general_fixed_floats(nfft, nmel) + (size_t)2 * stat_rows * numcep) * sizeof(float);
 }
 
 __device__ __forceinline__ unsigned bit_reverse(unsigned v, int bits) { return bits ? __brev(v) >> (32 - bits) : 0u; }
@@ -77,6 +95,38 @@ __device__ __forceinline__ float preemph_at(const T* __restrict__ x, int64_t g, 
   const float x1 = (float)x[g - 1];
   if (sizeof(T) == 2) return fmaf(-pre_lo, x1, fmaf(-pre_hi, x1, x0));
   return __fsub_rn(x0, __fmul_rn(pre_hi, x1));
+}
+
+// Tile end of both kernels: delta (mfcc-self5.py:169-179) of rows d_lo .. d_hi-1 of the static rows in LDS,
+// then delta of the deltas for the tile's own rows; both clamp their row indices to the utterance; rows out.
+__device__ __forceinline__ void general_tile_rows(const GeneralConst& gc, const float* stat, float* dlt, int s_lo, int t0, int nt, int nframes,
+                                                  float* out_rows, int64_t ld, int tid) {
+  const int ncep = gc.numcep, pf = gc.pad_fac;
+  __syncthreads();
+  const int d_lo = max(0, t0 - pf), d_hi = min(nframes, t0 + nt + pf);
+  const float denom = gc.delta_denom;
+  for (int i = tid; i < (d_hi - d_lo) * ncep; i += 256) {
+    const int r = d_lo + i / ncep, c = i % ncep;
+    float acc = 0.f;
+    for (int k = -pf; k <= pf; ++k) {
+      const int rr = min(max(r + k, 0), nframes - 1);
+      acc = fmaf((float)k, stat[(rr - s_lo) * ncep + c], acc);
+    }
+    dlt[(r - s_lo) * ncep + c] = acc / denom;
+  }
+  __syncthreads();
+  for (int i = tid; i < nt * ncep; i += 256) {
+    const int r = t0 + i / ncep, c = i % ncep;
+    float acc = 0.f;
+    for (int k = -pf; k <= pf; ++k) {
+      const int rr = min(max(r + k, 0), nframes - 1);
+      acc = fmaf((float)k, dlt[(rr - s_lo) * ncep + c], acc);
+    }
+    float* const o = out_rows + (int64_t)r * ld;   // out_rows = row 0 of the utterance
+    o[c] = stat[(r - s_lo) * ncep + c];
+    o[ncep + c] = dlt[(r - s_lo) * ncep + c];
+    o[2 * ncep + c] = acc / denom;
+  }
 }
 
 // TABLES_IN_LDS: the plan found room for the filter weights and the DCT matrix in LDS (both or
@@ -207,7 +257,7 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
       }
       const float v = mag ? 0.5f * sqrtf(p4) : p4 * (0.25f * gc.inv_nfft);
       srow[k] = v;
-      if (orow) orow[k] = out_kind == kOutLogspec ? logf(fmaxf(v, gc.log_floor)) : v;
+      if (orow) orow[k] = out_kind == kOutLogspec ? fast_ln(fmaxf(v, gc.log_floor)) : v;
     }
     wave_sync();
     if (out_kind == kOutSpec || out_kind == kOutLogspec) continue;
@@ -217,7 +267,7 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
     for (int k = lane; k < nbin; k += 64) e += srow[k];
     for (int m = 32; m >= 1; m >>= 1) e += __shfl_xor(e, m, 64);
     if (e == 0.f) e = kEps64;
-    const float lne = logf(e);
+    const float lne = fast_ln(e);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int j = lane + 64 * u;
@@ -235,7 +285,7 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
       }
       for (; k < hi; ++k) acc = fmaf(srow[k], w[k], acc);
       if (gc.floor_mel && acc == 0.f) acc = kEps64;
-      lrow[j] = logf(acc);
+      lrow[j] = fast_ln(acc);
     }
     wave_sync();
     const bool own = t >= t0 && t < t0 + nt;
@@ -267,33 +317,195 @@ __global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const
     wave_sync();
   }
   if (!full) return;
+  general_tile_rows(gc, stat, dlt, s_lo, t0, nt, nframes, p.out + f_off * ld, ld, tid);
+}
+
+// ---- FFT lengths up to 512: four frames per wave ------------------------------------------------------------
+template <typename T, bool TABLES_IN_LDS>
+__global__ void __launch_bounds__(256, 3) general16_kernel(const FusedParams p, const GeneralConst* __restrict__ gcp, int out_kind) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  const GeneralConst gc = *gcp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q_lane = lane & 15, g4 = lane >> 4;
+  const int nbin = (gc.nfft >> 1) + 1;
+  const int dshift = 8 - gc.log2m;            // log2(512 / nfft): bin j of the nfft-point transform = bin j << dshift of the 512-point one
+  const int dmask = (1 << dshift) - 1;
+  const int nmel = gc.nmel, ncep = gc.numcep, pf = gc.pad_fac;
+  const cf* const twl = (const cf*)gsm;       // [512] exp(-2 pi i m / 512)
+  float* const tables = gsm + 1024;           // [bankc_lds] filter weights, [dct_lds] DCT * lifter
+  typedef const float __attribute__((address_space(3))) * lds_cptr;
+  typedef const float __attribute__((address_space(1))) * glb_cptr;
+  typedef typename std::conditional<TABLES_IN_LDS, lds_cptr, glb_cptr>::type tab_cptr;
+  const tab_cptr bankw = TABLES_IN_LDS ? (tab_cptr)(uintptr_t)(lds_cptr)tables : (tab_cptr)(uintptr_t)gc.bankc;
+  const tab_cptr dctw = TABLES_IN_LDS ? (tab_cptr)(uintptr_t)(lds_cptr)(tables + gc.bankc_lds) : (tab_cptr)(uintptr_t)gc.dctl;
+  int32_t* const bandl = (int32_t*)(tables + gc.bankc_lds + gc.dct_lds);  // [nmel][3]
+  const int lpitch = general16_lrow_floats(nmel);
+  float* const wbase = (float*)bandl + general16_band_floats(nmel) + wave * general16_wave_floats(nmel);
+  float* const xch = wbase + g4 * 512;                          // this frame's exchange buffer, its spectrum row afterwards
+  float* const lrow = wbase + 4 * 512 + g4 * lpitch;            // [nmel] ln mel of this frame
+  float* const stat = (float*)bandl + general16_band_floats(nmel) + 4 * general16_wave_floats(nmel);  // [stat_rows][ncep]
+  float* const dlt = stat + gc.stat_rows * ncep;
+
+  const Tile tile = p.tiles[blockIdx.x];
+  const int64_t s_off = p.sample_off[tile.utt];
+  const int64_t len = p.sample_len ? p.sample_len[tile.utt] : p.sample_off[tile.utt + 1] - s_off;
+  const int64_t f_off = p.frame_off[tile.utt];
+  const int nframes = (int)(p.frame_off[tile.utt + 1] - f_off);
+  const int t0 = tile.t0, nt = tile.nt;
+  const bool full = out_kind == kOutMfcc39;
+  const int s_lo = full ? max(0, t0 - 2 * pf) : t0;
+  const int s_hi = full ? min(nframes, t0 + nt + 2 * pf) : t0 + nt;
+  const T* const x = (const T*)p.audio + s_off;
+  const int64_t ld = p.out_ld;
+  const bool mag = gc.spectrum != 0;
+  const bool pre_on = !(gc.pre_hi == 0.f && gc.pre_lo == 0.f);
+
+  for (int i = tid; i < 1024; i += 256) gsm[i] = gc.tw[i];
+  for (int i = tid; i < gc.bankc_lds; i += 256) tables[i] = gc.bankc[i];  // the plan pads bankc to this length
+  for (int i = tid; i < gc.dct_lds; i += 256) tables[gc.bankc_lds + i] = i < nmel * ncep ? gc.dctl[i] : 0.f;
+  for (int i = tid; i < 3 * nmel; i += 256) bandl[i] = gc.band[i];
   __syncthreads();
-  // ---- delta (mfcc-self5.py:169-179) of rows d_lo .. d_hi-1, then delta of the deltas for the
-  //      tile's own rows; both clamp their row indices to the utterance
-  const int d_lo = max(0, t0 - pf), d_hi = min(nframes, t0 + nt + pf);
-  const float denom = gc.delta_denom;
-  for (int i = tid; i < (d_hi - d_lo) * ncep; i += 256) {
-    const int r = d_lo + i / ncep, c = i % ncep;
-    float acc = 0.f;
-    for (int k = -pf; k <= pf; ++k) {
-      const int rr = min(max(r + k, 0), nframes - 1);
-      acc = fmaf((float)k, stat[(rr - s_lo) * ncep + c], acc);
+  const int partner_addr = ((lane & 48) | partner_lane(q_lane)) << 2;
+
+  for (int tq = s_lo + 4 * wave; tq < s_hi; tq += 16) {
+    // The lane's index inside its frame passes through an empty asm statement: everything derived from it below
+    // (sample offsets, window addresses, bin tests, twiddle addresses) is then computed where it is used -- hoisted
+    // out of this loop, as the compiler would do with values that do not change, they need more registers than there are.
+    int q = q_lane;
+    asm volatile("" : "+v"(q));
+    const int t = tq + g4;
+    const bool live = t < s_hi;  // frame slots past the tile's last frame transform zeros and store nothing
+    // ---- framing (mfcc-self5.py:85-95): samples t*step .. +used, zeros past the utterance end; point n = 16 n1 + q
+    //      of the packed frame z[n] = y[2n] + i y[2n+1].  Indices are clamped into the utterance so that every
+    //      load is legal; what lies outside is zeroed.
+    // 32-bit sample positions relative to the frame's first sample: lo_r = the utterance's first sample, hi_r = its last
+    const int64_t g0 = (int64_t)(live ? t : s_lo) * gc.frame_step;
+    const T* const xf = x + g0;
+    constexpr int64_t kFar = 1 << 29;
+    const int lo_r = (int)(g0 < kFar ? -g0 : -kFar), hi_r = (int)(len - 1 - g0 < kFar ? len - 1 - g0 : kFar);
+    cf xr[16];
+    // all loads of the frame first (one memory round trip per four frames; the kernel runs few waves per SIMD,
+    // so registers are not what limits it); registers beyond the frame's samples load clamped addresses and are zeroed
+    T rm[16], ra[16], rb[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int i = 2 * (16 * n1 + q);
+      rm[n1] = xf[min(max(i - 1, lo_r), hi_r)];
+      ra[n1] = xf[min(i, hi_r)];
+      rb[n1] = xf[min(i + 1, hi_r)];
     }
-    dlt[(r - s_lo) * ncep + c] = acc / denom;
-  }
-  __syncthreads();
-  for (int i = tid; i < nt * ncep; i += 256) {
-    const int r = t0 + i / ncep, c = i % ncep;
-    float acc = 0.f;
-    for (int k = -pf; k <= pf; ++k) {
-      const int rr = min(max(r + k, 0), nframes - 1);
-      acc = fmaf((float)k, dlt[(rr - s_lo) * ncep + c], acc);
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int i = 2 * (16 * n1 + q);
+      const float xm = (float)rm[n1], xa = (float)ra[n1], xb = (float)rb[n1];
+      // y[0] = x[0], y[n] = x[n] - c x[n-1] (mfcc-self5.py:68), two-term coefficient for int16 samples
+      auto emph = [&](float cur, float prev, bool first) {
+        if (first || !pre_on) return cur;
+        if (sizeof(T) == 2) return fmaf(-gc.pre_lo, prev, fmaf(-gc.pre_hi, prev, cur));
+        return __fsub_rn(cur, __fmul_rn(gc.pre_hi, prev));
+      };
+      float y0 = (live && i < gc.used && i <= hi_r) ? emph(xa, xm, i == lo_r) : 0.f;
+      float y1 = (live && i + 1 < gc.used && i + 1 <= hi_r) ? emph(xb, xa, false) : 0.f;
+      if (gc.window) {
+        y0 *= gc.window[min(i, gc.frame_size - 1)];
+        y1 *= gc.window[min(i + 1, gc.frame_size - 1)];
+      }
+      xr[n1] = mk(y0, y1);
     }
-    float* const o = p.out + (f_off + r) * ld;
-    o[c] = stat[(r - s_lo) * ncep + c];
-    o[ncep + c] = dlt[(r - s_lo) * ncep + c];
-    o[2 * ncep + c] = acc / denom;
+    // ---- 512-point transform of the zero-padded frame on 16 lanes (fft_lane.h)
+    fft16(xr);
+    cf* const xc = (cf*)xch;
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+      if (k1) xr[k1] = cmul(xr[k1], twl[(2 * q * k1) & 511]);  // W256^(q k1)
+      xc[xpose_index(k1, q)] = xr[k1];
+    }
+    wave_sync();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) xr[n2] = xc[xpose_index(q, n2)];
+    fft16(xr);
+    wave_sync();  // every lane has read its row before the spectrum row overwrites the buffer
+    // ---- untangle into the frame's spectrum row: value |X|^2 / nfft or |X| (mfcc-self5.py:96-97) of every
+    //      (512 / nfft)-th bin
+    float* const orow = (out_kind == kOutSpec || out_kind == kOutLogspec) && live && t >= t0 ? p.out + (f_off + t) * ld : nullptr;
+    auto put = [&](int k, float p4) {
+      if (k & dmask) return;
+      const float v = mag ? 0.5f * __builtin_amdgcn_sqrtf(p4) : p4 * (0.25f * gc.inv_nfft);
+      xch[k >> dshift] = v;
+      if (orow) orow[k >> dshift] = out_kind == kOutLogspec ? fast_ln(fmaxf(v, gc.log_floor)) : v;
+    };
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      cf pb = mk(lane_read(partner_addr, xr[15 - s].x), lane_read(partner_addr, xr[15 - s].y));
+      if (q == 0) pb = xr[(16 - s) & 15];  // lane 0 pairs inside itself
+      float lo, hi2;
+      untangle_power(xr[s], pb, twl[q + 16 * s], lo, hi2);
+      put(q + 16 * s, lo);
+      put(256 - q - 16 * s, hi2);
+    }
+    if (q == 0) put(128, 4.f * norm2(xr[8]));
+    wave_sync();
+    if (out_kind == kOutSpec || out_kind == kOutLogspec) continue;
+    // ---- mel energies and frame energy (mfcc-self5.py:119-134) on the frame's 16 lanes: ln of the unfloored band
+    //      sums (-inf on an empty band) unless floor_mel; ln E floored at the float64 epsilon
+    float e = 0.f;
+    for (int k = q; k < nbin; k += 16) e += xch[k];
+    e += row_ror<8>(e);
+    e += row_ror<4>(e);
+    e += row_ror<2>(e);
+    e += row_ror<1>(e);
+    if (e == 0.f) e = kEps64;
+    const float lne = fast_ln(e);
+    for (int j = q; j < nmel; j += 16) {
+      const int lo = bandl[3 * j], hi3 = bandl[3 * j + 1];
+      const tab_cptr w = bankw + bandl[3 * j + 2] - lo;  // w[k] = weight of bin k, lo <= k < hi
+      float acc = 0.f;
+      int k = lo;
+      for (; k + 4 <= hi3; k += 4) {  // four weights in flight; the sum keeps the order of the bins
+        const float w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
+        acc = fmaf(xch[k], w0, acc);
+        acc = fmaf(xch[k + 1], w1, acc);
+        acc = fmaf(xch[k + 2], w2, acc);
+        acc = fmaf(xch[k + 3], w3, acc);
+      }
+      for (; k < hi3; ++k) acc = fmaf(xch[k], w[k], acc);
+      if (gc.floor_mel && acc == 0.f) acc = kEps64;
+      lrow[j] = fast_ln(acc);
+    }
+    wave_sync();
+    const bool own = live && t >= t0 && t < t0 + nt;
+    if (out_kind == kOutLogmel) {
+      if (own) {
+        float* const o = p.out + (f_off + t) * ld;
+        for (int j = q; j < nmel; j += 16) o[j] = lrow[j];
+        if (q == 0) o[nmel] = lne;
+      }
+      wave_sync();
+      continue;
+    }
+    // ---- DCT-II * lifter, c0 := ln E (mfcc-self5.py:136-167)
+    for (int c = q; c < ncep; c += 16) {
+      float acc = 0.f;
+      int n = 0;
+      for (; n + 4 <= nmel; n += 4) {
+        const float w0 = dctw[n * ncep + c], w1 = dctw[(n + 1) * ncep + c], w2 = dctw[(n + 2) * ncep + c], w3 = dctw[(n + 3) * ncep + c];
+        acc = fmaf(lrow[n], w0, acc);
+        acc = fmaf(lrow[n + 1], w1, acc);
+        acc = fmaf(lrow[n + 2], w2, acc);
+        acc = fmaf(lrow[n + 3], w3, acc);
+      }
+      for (; n < nmel; ++n) acc = fmaf(lrow[n], dctw[n * ncep + c], acc);
+      if (c == 0 && !gc.keep_c0) acc = lne;
+      if (full) {
+        if (live) stat[(t - s_lo) * ncep + c] = acc;
+      } else if (own) {
+        p.out[(f_off + t) * ld + c] = acc;
+      }
+    }
+    wave_sync();
   }
+  if (!full) return;
+  general_tile_rows(gc, stat, dlt, s_lo, t0, nt, nframes, p.out + f_off * ld, ld, tid);
 }
 
 }  // namespace mfcc

@@ -264,7 +264,15 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
   if (plan->general) {
     // the public out_kind values are the kernel's own
     const bool lds_tables = plan->gc_host.bankc_lds > 0 && plan->gc_host.dct_lds > 0;
-    if (lds_tables) {
+    if (plan->gc_host.lane16) {
+      if (lds_tables) {
+        if (i16) hipLaunchKernelGGL((mfcc::general16_kernel<int16_t, true>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+        else hipLaunchKernelGGL((mfcc::general16_kernel<float, true>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+      } else {
+        if (i16) hipLaunchKernelGGL((mfcc::general16_kernel<int16_t, false>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+        else hipLaunchKernelGGL((mfcc::general16_kernel<float, false>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+      }
+    } else if (lds_tables) {
       if (i16) hipLaunchKernelGGL((mfcc::general_kernel<int16_t, true>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
       else hipLaunchKernelGGL((mfcc::general_kernel<float, true>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
     } else {
@@ -547,7 +555,7 @@ static int build_general(mfcc_plan* p) {
   // LDS budget: 64 KiB per workgroup.  The twiddles and the four waves' buffers always live there;
   // the filter weights and the DCT matrix join them when the tile's static and delta rows still
   // get a useful share of the rest (they are read from global memory otherwise).
-  const size_t fixed_bytes = ((size_t)nfft + (size_t)4 * mfcc::general_wave_floats(nfft, nmel)) * sizeof(float);
+  const size_t fixed_bytes = mfcc::general_fixed_floats(nfft, nmel) * sizeof(float);
   const size_t row_bytes = (size_t)2 * ncep * sizeof(float);
   const size_t want_rows = (size_t)4 * pf + 32;
   size_t table_floats = 0;
@@ -561,6 +569,13 @@ static int build_general(mfcc_plan* p) {
   }
   const int64_t rows_fit = ((int64_t)65536 - (int64_t)fixed_bytes - (int64_t)(table_floats * sizeof(float))) / (int64_t)row_bytes;
   int rows = (int)std::min<int64_t>(rows_fit, mfcc::kGenMaxTile + 4 * pf);
+  if (nfft <= mfcc::kNfft) {
+    // The four-frames-per-wave kernel waits on memory and LDS round trips more than on arithmetic: a third
+    // workgroup per CU (LDS <= 42 of the CU's 128 allocation units) is worth more than tiles of 128 frames,
+    // as long as a tile still holds 48.
+    const int64_t rows3 = ((int64_t)42 * 1280 - (int64_t)fixed_bytes - (int64_t)(table_floats * sizeof(float))) / (int64_t)row_bytes;
+    if (rows3 - 4 * pf >= 48) rows = (int)std::min<int64_t>(rows, rows3);
+  }
   if (rows - 4 * pf < 4) {
     // Too little LDS left for the static and delta rows of even a four-frame tile (e.g. 2048-point FFT,
     // 128 filters, 64 cepstra): only the MFCC-39 kind uses those rows, so the plan serves every other
@@ -581,7 +596,8 @@ static int build_general(mfcc_plan* p) {
     win.assign(h.begin(), h.end());
   }
   int rc;
-  if ((rc = upload(mfcc::twiddle_half(nfft), &p->g_tw)) || (rc = upload(bankc, &p->g_bank)) || (rc = upload(band, &p->g_band)) ||
+  const bool lane16 = nfft <= mfcc::kNfft;  // the four-frames-per-wave kernel on the 512-point register transform
+  if ((rc = upload(lane16 ? mfcc::twiddle512() : mfcc::twiddle_half(nfft), &p->g_tw)) || (rc = upload(bankc, &p->g_bank)) || (rc = upload(band, &p->g_band)) ||
       (rc = upload(dlf, &p->g_dctl)) || (rc = upload(win, &p->g_window)))
     return rc;
   mfcc::GeneralConst& g = p->gc_host;
@@ -613,6 +629,7 @@ static int build_general(mfcc_plan* p) {
   g.delta_denom = (float)denom;
   g.keep_c0 = cfg->keep_c0 ? 1 : 0;
   g.stat_rows = rows;
+  g.lane16 = lane16 ? 1 : 0;
   if ((rc = upload(std::vector<mfcc::GeneralConst>(1, g), &p->gc))) return rc;
   p->general = true;
   return MFCC_OK;
