@@ -278,7 +278,8 @@ def run_config_d(args, rank, world, dev, torch, mfcc_amd, dist):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         events = {}
-        feats, sums, mm, vv = mfcc_amd.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=out, events=events)
+        feats, sums, mm, vv = mfcc_amd.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=out, events=events,
+                                                        overlap=args.overlap)
         step_events.append(events)   # read after the clock stops: querying ~70 event pairs takes about 2 ms of host time
     torch.cuda.synchronize()
     if world > 1:
@@ -330,6 +331,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the compact config C / E figures")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for N > 1: nccl = RCCL over xGMI (default); gloo lets N ranks share one GPU (tests)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="config D: per-chunk statistics passes on a second stream beside the next chunk's extraction, instead of "
+                         "one pass after the last chunk (measured slower: the two kernels share the CUs, profiles/r3_configD_*.json)")
     ap.add_argument("--no-precondition", action="store_true", help="skip the untimed clock-ramp launches in front of the warm-up")
     args = ap.parse_args()
     # Defaults of config B: the part ramps its clocks up over the first ~35 launches of a cold start

@@ -16,14 +16,27 @@ import torch
 from . import frontend as F
 
 
+_side_streams = {}
+
+
+def _side_stream(dev):
+    s = _side_streams.get(dev.index)
+    if s is None:
+        s = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None, ddof=0, events=None, static_scratch=False,
-                     per_chunk_sums=False):
+                     per_chunk_sums=False, overlap=False):
     """fe: MFCC extractor; audio: this rank's packed device samples; lengths: its utterance
     lengths.  Returns (feats [sum F, D] normalised in place, sums float64[1 + 2 D] of the whole
     corpus, mm, vv).  ``events``: optional dict that receives per-phase lists of (start, end)
     torch.cuda.Event pairs recorded on the current stream (phases: forward, accumulate, exchange,
     apply).  ``per_chunk_sums``: accumulate the statistics after every chunk (while its rows are still in
-    the caches) instead of in one pass after the last chunk."""
+    the caches) instead of in one pass after the last chunk.  ``overlap``: the same per-chunk accumulation on a
+    second stream, ordered behind its chunk's extraction by an event, so that the memory-bound statistics pass
+    runs beside the arithmetic-bound extraction of the next chunk; the sums are added chunk by chunk in chunk
+    order either way (equal inputs give equal bits)."""
     lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
     plan = fe.plan
     counts = np.array([plan.frames_for_length(int(n)) for n in lengths], dtype=np.int64) if len(set(lengths.tolist())) > 1 \
@@ -48,6 +61,10 @@ def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None,
 
     s_pos = f_pos = 0
     with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if overlap else None
+        if side is not None:
+            side.wait_stream(main)      # `sums` was zeroed on the main stream
         for u0 in range(0, len(lengths), chunk_utts):
             ls = lengths[u0:u0 + chunk_utts]
             ns, nf = int(ls.sum()), int(counts[u0:u0 + chunk_utts].sum())
@@ -56,13 +73,21 @@ def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None,
             e = mark("forward")
             fe.forward(audio[s_pos:s_pos + ns], lay, out=view)
             if e: e.record()
-            if per_chunk_sums:
+            if side is not None:
+                side.wait_stream(main)  # behind this chunk's extraction; the next chunk's runs beside it
+                with torch.cuda.stream(side):
+                    e = mark("accumulate")
+                    F.cmvn_accumulate(view[:, :d], sums, static=static_scratch)
+                    if e: e.record()
+            elif per_chunk_sums:
                 e = mark("accumulate")
                 F.cmvn_accumulate(view[:, :d], sums, static=static_scratch)
                 if e: e.record()
             s_pos += ns
             f_pos += nf
-        if not per_chunk_sums:
+        if side is not None:
+            main.wait_stream(side)
+        elif not per_chunk_sums:
             # the rows are all resident: one pass over them (the extraction launches then run back to back)
             e = mark("accumulate")
             F.cmvn_accumulate(feats, sums, static=static_scratch)

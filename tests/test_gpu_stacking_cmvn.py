@@ -376,3 +376,9 @@ def test_corpus_pipeline_statistics_per_chunk_or_at_the_end(M):
         assert np.allclose(other[1].cpu().numpy(), a[1].cpu().numpy(), rtol=1e-12, atol=1e-7)
         assert (other[0] - a[0]).abs().max() < 1e-5
     assert torch.equal(a[0], c[0])    # one pass over the same rows in the same order: same bits, whatever the chunking
+    # the per-chunk passes on a second stream, beside the next chunk's extraction: the bits of the per-chunk passes in line
+    for _ in range(3):
+        o = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=7, overlap=True)
+        assert torch.equal(o[1], b[1]) and torch.equal(o[0], b[0])
+    o = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=7, overlap=True, static_scratch=True)
+    assert torch.equal(o[1], b[1]) and torch.equal(o[0], b[0])
