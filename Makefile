@@ -24,7 +24,7 @@ variant: $(SRC) $(HDRS)
 
 asm: $(SRC) $(HDRS)
 	@mkdir -p build
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-signed-zeros -fno-slp-vectorize -S --cuda-device-only -o build/mfcc_amd.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-signed-zeros -fno-slp-vectorize $(EXTRA) -S --cuda-device-only -o build/mfcc_amd.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
 
 clean:
 	rm -rf mfcc_amd/lib build tests/host_sim/fft_sim

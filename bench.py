@@ -122,7 +122,7 @@ def precondition(step, torch, cap=100, window=10):
     """Untimed clock-ramp phase, separate from (and in front of) the --warmup launches: a cold part
     raises its clocks over the first few dozen launches of this kernel, and a short run would time the
     ramp instead of the kernel.  Launches run in windows of `window`; the phase ends when the median
-    launch time of a window is within 1 % of the window before it, or after `cap` launches."""
+    launch times of three windows in a row agree within 1 %, or after `cap` launches."""
     medians, first, last, n = [], None, None, 0
     while n < cap:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(window)]
@@ -136,7 +136,7 @@ def precondition(step, torch, cap=100, window=10):
         first = w[0] if first is None else first
         last = w[-1]
         medians.append(sorted(w)[len(w) // 2])
-        if len(medians) >= 2 and abs(medians[-1] - medians[-2]) <= 0.01 * medians[-2]:
+        if len(medians) >= 3 and max(medians[-3:]) - min(medians[-3:]) <= 0.01 * min(medians[-3:]):
             break
     return {"preconditioning_launches": n, "first_launch_ms": round(first, 4), "last_launch_ms": round(last, 4),
             "window_median_ms": [round(m, 4) for m in medians],

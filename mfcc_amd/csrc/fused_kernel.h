@@ -305,6 +305,20 @@ struct FusedParams {
 #define MFCC_STAMP(var)
 #endif
 
+// Phase marks for tools/isa_phases.py (build with -DMFCC_PHASE_MARKS, assembly only): a comment line in the
+// instruction stream wherever a phase of the batch loop begins.  They may shift the compiler's schedule a
+// little, so the product is built without them.
+#ifdef MFCC_PHASE_MARKS
+#define MFCC_PHASE(name)                    \
+  do {                                      \
+    __builtin_amdgcn_sched_barrier(0);      \
+    asm volatile("; MFCC_PHASE " name);     \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+#else
+#define MFCC_PHASE(name)
+#endif
+
 enum : int { kOutMfcc39 = 0, kOutStatic = 1, kOutLogmel = 2, kOutSpec = 3, kOutLogspec = 4,
              kOutSpecStack = 5, kOutLogspecStack = 6,    // spectrum rows stacked over N frames (context windows)
              // One push of B live streams in one launch, workgroup b = stream b: append the chunk to the
@@ -640,6 +654,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       d[4] = regress(pe[2].x, pe[2].y, pe[3].x, pe[3].y, po[3].y);
     } else {
       asm volatile("" ::: "memory");  // keeps this rare path a real branch: nothing of it is hoisted
+      MFCC_PHASE("cold: rows near an utterance end");
 #pragma unroll
       for (int m = 0; m < 9; ++m) {
         const int t = min(max(r - kHalo + m, 0), nframes - 1);
@@ -732,6 +747,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   MFCC_STAMP(tk0);
 #endif
   for (int tb = s_lo; tb < s_hi; tb += kBatch) {
+    MFCC_PHASE("1 frame load (staged samples -> registers)");
     MFCC_STAMP(ta);
     __builtin_amdgcn_s_setprio(MFCC_PRIO_FFT);
     // spectrum kinds have no filterbank phase to cover the staging loads of the next batch: they fly
@@ -743,6 +759,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       const float* fa = abuf + delta + fb * G::kStep;
       cf x[16];
       if (delta & 1) {  // odd sample offset: the (x[2n], x[2n+1]) pairs are not 8-byte aligned in LDS
+        MFCC_PHASE("cold: frame load at an odd sample offset");
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
           const int n = 16 * n1 + q;
@@ -797,6 +814,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         }
       }
       if (window) {
+        MFCC_PHASE("cold: window");
         // all window loads first (they hit L1/L2), then the products: one wait instead of 13
         cf wv[(G::kSize + 31) / 32];
 #pragma unroll
@@ -806,6 +824,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       }
       // stage-1 twiddles of this lane: read now (their latency hides under the first 16-point
       // transform); reading them between the exchange writes would serialise on LDS round trips
+      MFCC_PHASE("2 transform pass 1 (pruned 16-point, stage twiddles, exchange write)");
       cf tw1[16];
       {
         const float4* const tv = (const float4*)__builtin_assume_aligned(twq + kTwSt1, 16);
@@ -834,6 +853,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #endif
         *(cf*)(lds0 + (wbase ^ ((k1 & 14) << 3)) + k1 * 128) = x[k1];
       }
+      MFCC_PHASE("3 transform pass 2 (exchange read, 16-point)");
       wave_sync();
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -846,6 +866,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #endif
       wave_sync();  // every lane of this wave has read its row before spectrum rows overwrite it
 
+      MFCC_PHASE("4 untangle, spectrum rows to LDS, energy sum");
       if (!kSpecOut) {
         // fetch the filterbank operands of this wave now (L2 latency ~ the untangle below)
 #pragma unroll
@@ -917,6 +938,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           if (mag) {
             // magnitude spectrum (mfcc-self15.py:234): one branch per group, so that the power path
             // does not pay for the square roots
+            MFCC_PHASE("cold: magnitude square roots");
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -960,6 +982,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     stage_ld(tb + kBatch);
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    MFCC_PHASE("5 barrier 1");
     MFCC_STAMP(tb1);
     __syncthreads();  // spectrum rows complete; staged audio no longer needed
     MFCC_STAMP(tb2);
@@ -1108,6 +1131,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 
     // ---- mel filterbank on the matrix cores: D[frame][col] = sum_bin P[frame][bin] W[bin][col]
 #if !defined(MFCC_ABL_STAGE) && !defined(MFCC_EARLY_STAGE)
+    MFCC_PHASE("6 next batch's global loads, filterbank operand reads");
     stage_ld(tb + kBatch);  // unconditional and branch-free; HBM latency runs under the MFMAs below
     __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the matrix-core chain
 #endif
@@ -1140,6 +1164,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         if (s >= nslots_now) break;  // wave-uniform
         unsigned info = slot_info[s];
         asm volatile("" : "+s"(info));
+        MFCC_PHASE("7 filterbank slot (x23 per workgroup and batch, 5-6 per wave)");
         if (info & kSlotFirst) {
           acc = f32x4{0.f, 0.f, 0.f, 0.f};
           acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1151,6 +1176,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][2], pa[s][2], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][3], pa[s][3], acc2, 0, 0, 0);
         if (info & kSlotLast) {
+          MFCC_PHASE("8 group end: reduce, log2, DCT k-steps (x7 per workgroup and batch)");
           // the group's sums: the four blocks of a row each walked a quarter of the bins
           f32x4 mv = acc + acc2;
 #pragma unroll
@@ -1162,6 +1188,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           if (floor_mel) {
             // a real branch on the wave-uniform flag (written as a select, the compare and the select
             // would run in the unfloored default too)
+            MFCC_PHASE("cold: mel floor");
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 4; ++r) mv[r] = mv[r] == 0.f ? kEps64 : mv[r];
@@ -1194,16 +1221,20 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
 #else
       pd[0] = Prow[0]; pd[1] = Prow[16]; pd[2] = bv[0][0]; pd[3] = bv[1][1];
 #endif
+      MFCC_PHASE("9 DCT share to LDS, rows out (delta, delta-delta, stores)");
       if (OUT != kOutLogmel) *(f32x4*)__builtin_assume_aligned(xbuf + part_index(frm, wave, 4 * blk), 16) = pd;
     }
     // rows of the batch before last whose +-4-row context is now complete leave as whole output rows
     if (kRows39 && tb > s_lo) emit_rows(tb - kBatch - kHalo);
+    MFCC_PHASE("10 staging: convert, pre-emphasis, LDS write");
     MFCC_STAMP(tb3);
 #ifndef MFCC_ABL_STAGE
     if (more) delta = stage_st(tb + kBatch);
 #endif
+    MFCC_PHASE("11 barrier 2");
     MFCC_STAMP(tb4);
     __syncthreads();  // ln-mel rows and energy partials complete; next batch staged
+    MFCC_PHASE("12 share sum, c0 := ln E, statics ring");
     MFCC_STAMP(tb5);
     __builtin_amdgcn_s_setprio(MFCC_PRIO_P3);
 
