@@ -124,7 +124,7 @@ int32_t mfcc_plan_kernel(const mfcc_plan* plan);
 /* 1 if mfcc_forward serves out_kind on this plan, 0 if not.  Every plan serves every kind with one
  * exception: a general-kernel plan whose FFT buffers and filter rows leave no room in a workgroup's
  * 64 KiB of LDS for the static and delta rows of a tile (2 * numcep floats for each of 4 + 4 * pad_fac
- * rows; e.g. num_fft 2048 with 128 filters and 64 cepstra) has no fused MFCC_OUT_MFCC39: take
+ * rows; e.g. num_fft 2048 with 128 filters, 64 cepstra and pad_fac 9) has no fused MFCC_OUT_MFCC39: take
  * MFCC_OUT_STATIC and apply mfcc_delta (delta, mfcc-self5.py:169-179) per utterance. */
 int32_t mfcc_plan_supports(const mfcc_plan* plan, int32_t out_kind);
 

@@ -272,12 +272,21 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
         if (i16) hipLaunchKernelGGL((mfcc::general16_kernel<int16_t, false>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
         else hipLaunchKernelGGL((mfcc::general16_kernel<float, false>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
       }
-    } else if (lds_tables) {
-      if (i16) hipLaunchKernelGGL((mfcc::general_kernel<int16_t, true>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
-      else hipLaunchKernelGGL((mfcc::general_kernel<float, true>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
     } else {
-      if (i16) hipLaunchKernelGGL((mfcc::general_kernel<int16_t, false>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
-      else hipLaunchKernelGGL((mfcc::general_kernel<float, false>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);
+      // 1024 points: 32 lanes per frame (R = 2); 2048 points: 64 lanes per frame (R = 4)
+#define MFCC_LAUNCH_W(R)                                                                                                                      \
+  do {                                                                                                                                        \
+    if (lds_tables) {                                                                                                                         \
+      if (i16) hipLaunchKernelGGL((mfcc::generalw_kernel<int16_t, true, R>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);   \
+      else hipLaunchKernelGGL((mfcc::generalw_kernel<float, true, R>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);         \
+    } else {                                                                                                                                  \
+      if (i16) hipLaunchKernelGGL((mfcc::generalw_kernel<int16_t, false, R>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);  \
+      else hipLaunchKernelGGL((mfcc::generalw_kernel<float, false, R>), grid, block, plan->gen_smem, st, fp, plan->gc, (int)out_kind);        \
+    }                                                                                                                                         \
+  } while (0)
+      if (plan->nfft == 1024) MFCC_LAUNCH_W(2);
+      else MFCC_LAUNCH_W(4);
+#undef MFCC_LAUNCH_W
     }
     return;
   }
@@ -569,8 +578,8 @@ static int build_general(mfcc_plan* p) {
   }
   const int64_t rows_fit = ((int64_t)65536 - (int64_t)fixed_bytes - (int64_t)(table_floats * sizeof(float))) / (int64_t)row_bytes;
   int rows = (int)std::min<int64_t>(rows_fit, mfcc::kGenMaxTile + 4 * pf);
-  if (nfft <= mfcc::kNfft) {
-    // The four-frames-per-wave kernel waits on memory and LDS round trips more than on arithmetic: a third
+  {
+    // The general kernels wait on memory and LDS round trips more than on arithmetic: a third
     // workgroup per CU (LDS <= 42 of the CU's 128 allocation units) is worth more than tiles of 128 frames,
     // as long as a tile still holds 48.
     const int64_t rows3 = ((int64_t)42 * 1280 - (int64_t)fixed_bytes - (int64_t)(table_floats * sizeof(float))) / (int64_t)row_bytes;

@@ -210,14 +210,15 @@ def test_layouts_and_plans_of_different_framings_do_not_mix(M):
 
 
 def test_largest_tables_leave_no_room_for_delta_rows(M):
-    """2048-point FFT, 128 filters, 64 cepstra: the FFT buffers and filter rows fill a workgroup's LDS, so
+    """2048-point FFT, 128 filters, 64 cepstra, pad_fac 9: the FFT buffers and filter rows leave too little of a
+    workgroup's LDS for the static and delta rows of even a four-frame tile with its 36 halo rows, so
     the plan has no fused MFCC-39 (mfcc_plan_supports says so, mfcc_forward refuses it with a clear
     error) but serves every other kind; the Python front-end builds MFCC-39 from the static rows and
     mfcc_delta per utterance."""
     import ctypes as C
     from mfcc_amd import _capi as capi
     a, b = _synth(91, 30000), _synth(92, 9000)
-    fe = M.MFCC("self5", fs=44100, frame_time=40, step_time=10, num_bins=128, numcep=64)
+    fe = M.MFCC("self5", fs=44100, frame_time=40, step_time=10, num_bins=128, numcep=64, pad_fac=9)
     assert fe.plan.general and fe.plan.num_fft == 2048
     lib = capi.load()
     assert lib.mfcc_plan_supports(fe.plan._h, capi.OUT_MFCC39) == 0
@@ -234,12 +235,60 @@ def test_largest_tables_leave_no_room_for_delta_rows(M):
         _mag, pw, _w, nfft = O.winfft(O.preemphasis(x), fs=44100, frame_time=40, step_time=10, loop=False)
         logmel, loge = O.melspec(pw, O.melbanks(44100, 128, 0, nfft), loop=False)
         static = O.staticfeatures(loge, O.dctopt(O.dct_ortho(logmel, 64, loop=False), 22))
-        d = O.delta(static, loop=False)
-        ref = O.spectrograms(static, d, O.delta(d, loop=False))
-        assert_cep(got[pos:pos + ref.shape[0]], ref, "2048-point, 128 filters, 64 cepstra")
+        d = O.delta(static, 9, loop=False)
+        ref = O.spectrograms(static, d, O.delta(d, 9, loop=False))
+        assert_cep(got[pos:pos + ref.shape[0]], ref, "2048-point, 128 filters, 64 cepstra, pad_fac 9")
         pos += ref.shape[0]
     assert pos == got.shape[0]
-    # a long regression window on a small plan still fuses (numcep 13, pad_fac 14 was refused before)
-    fe2 = M.MFCC("self5", fs=44100, frame_time=40, step_time=10, num_bins=128, numcep=13, pad_fac=14)
-    assert lib.mfcc_plan_supports(fe2.plan._h, capi.OUT_MFCC39) in (0, 1)
-    fe2(a)
+    # the same tables with the default regression window fuse, and so does a long window on narrow rows
+    for kw in (dict(numcep=64), dict(numcep=13, pad_fac=14)):
+        fe2 = M.MFCC("self5", fs=44100, frame_time=40, step_time=10, num_bins=128, **kw)
+        assert lib.mfcc_plan_supports(fe2.plan._h, capi.OUT_MFCC39) == 1
+        assert torch.isfinite(fe2(packed, lengths=[len(a), len(b)])).all()
+
+
+@pytest.mark.parametrize("fs,nfft", [(22050, 1024), (32000, 1024), (48000, 2048), (44100, 2048)])
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_1024_and_2048_point_plans_against_the_oracle(M, fs, nfft, variant):
+    """The frames of 22.05 / 32 kHz (551 / 800 samples, 1024-point FFT: 32 lanes per frame, two frames per wave) and of
+    44.1 / 48 kHz (1102 / 1200 samples, 2048 points: 64 lanes per frame) on a ragged batch with frame-count edge cases
+    (one sample, one frame, one sample more than a frame, several tiles): every kind against the oracle's stages."""
+    size, step, n = O.frame_geometry(fs, 25, 10)
+    assert n == nfft
+    lengths = [1, size - 1, size, size + 1, size + step, 9 * step + size + 7, 150 * step + 11, 333 * step]
+    audios = [_synth(500 + i, L) for i, L in enumerate(lengths)]
+    fe = M.MFCC(variant, fs=fs)
+    assert fe.plan.general and fe.plan.num_fft == nfft
+    packed = torch.from_numpy(np.concatenate(audios)).cuda()
+    lay = fe.layout(lengths)
+    out = fe.forward(packed, lay).cpu().numpy()
+    lm = fe.forward(packed, lay, kind="logmel").cpu().numpy()
+    st = fe.forward(packed, lay, kind="static").cpu().numpy()
+    spec = fe.forward(packed, lay, kind="spec").cpu().numpy()
+    assert spec.shape[1] == nfft // 2 + 1
+    for u, a in enumerate(audios):
+        r0, r1 = lay.frame_offsets[u], lay.frame_offsets[u + 1]
+        ref = O.mfcc39(a, variant, fs=fs, return_stages=True)
+        assert r1 - r0 == ref["out"].shape[0] == O.frame_count(len(a), size, step)
+        assert_cep(out[r0:r1], ref["out"], f"fs={fs} {variant} L={len(a)}")
+        assert_cep(st[r0:r1], ref["out"][:, :13], f"fs={fs} {variant} static L={len(a)}")
+        assert_logmel(lm[r0:r1, :26], ref["logmel"], f"fs={fs} {variant} ln-mel L={len(a)}")
+        assert_logmel(lm[r0:r1, 26], ref["loge"], f"fs={fs} {variant} ln-E L={len(a)}")
+        sref = ref["pow"] if variant == "self5" else ref["mag"]
+        assert (np.abs(spec[r0:r1] - sref) <= 2e-6 * np.abs(sref).max(axis=1, keepdims=True)).all()
+    outf = fe(packed.to(torch.float32), lengths=lengths).cpu().numpy()
+    assert_cep(outf, out, f"fs={fs} float input", atol=2e-3 if variant == "self5" else 1e-3)
+    # Hamming window (the extension) and another pad_fac / filterbank on the same kernel, against the oracle's pieces
+    a = audios[-2]
+    few = M.MFCC(variant, fs=fs, window="hamming", num_bins=40, numcep=20, pad_fac=3)
+    got = few(a)
+    pre = O.preemphasis(a) if variant == "self5" else a.astype(np.float64)
+    nf = O.frame_count(len(a), size, step)
+    padded = np.concatenate([pre, np.zeros((nf - 1) * step + size - len(a))])
+    frames = padded[np.arange(nf)[:, None] * step + np.arange(size)[None, :]] * np.hamming(size)
+    mag = np.abs(np.fft.rfft(frames, nfft, axis=1))
+    pw = mag ** 2 / nfft
+    logmel, loge = O.melspec(pw if variant == "self5" else mag, O.melbanks(fs, 40, 0, nfft), loop=False)
+    static = O.staticfeatures(loge, O.dctopt(O.dct_ortho(logmel, 20, loop=False), 22))
+    d = O.delta(static, 3, loop=False)
+    assert_cep(got, O.spectrograms(static, d, O.delta(d, 3, loop=False)), f"fs={fs} hamming, 40 filters, 20 cepstra, pad_fac 3")
