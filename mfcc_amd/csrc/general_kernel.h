@@ -1,8 +1,8 @@
 // General-geometry MFCC kernel: the same pipeline as fused_kernel.h for every framing the
 // reference's winfft can derive (frame_size = int(fs * frame_time / 1000), num_fft = next power of
 // two, mfcc-self5.py:75-84), any pad_fac of delta (:169-179) and filterbank / cepstrum sizes the
-// specialised kernel has no template for.  Built to be right for every valid call, not to be fast:
-// the 400/160/512 and 200/80/512 framings of the reference's own scripts run in fused_kernel.h.
+// specialised kernel has no template for.  The 400/160/512 and 200/80/512 framings of the
+// reference's own scripts run in fused_kernel.h, about three times faster per frame.
 //
 // Work decomposition
 //   grid       one workgroup (4 waves) per tile of consecutive output frames of one utterance
@@ -13,14 +13,14 @@
 //              frame; the samples come straight from global memory, everything after the transform
 //              (filters, ln, DCT) runs on the frame's 16 lanes out of the wave's own LDS rows, so the
 //              waves of a workgroup never wait for each other until the tile's rows are complete.
-//              Longer FFTs (general_kernel):
-//              one frame at a time: the frame_size samples are read from global memory
-//              (pre-emphasised on the fly, zero beyond the utterance end), packed as nfft/2
-//              complex points z[n] = x[2n] + i x[2n+1] into the wave's own LDS buffer in
-//              bit-reversed order, transformed by radix-2 butterflies in LDS (a wave's LDS
-//              operations execute in program order, so no workgroup barrier is needed), untangled
-//              into the nfft/2+1 spectrum values, reduced by the sparse triangular filters (one
-//              lane per filter), ln, DCT-II * lifter (one lane per coefficient);
+//              1024 and 2048 points (generalw_kernel): L = nfft / 32 lanes per frame (two frames or one per
+//              wave).  The frame is packed as M = nfft / 2 complex points z[n] = x[2n] + i x[2n+1]; M = 16 * 16 * R
+//              (R = 2 or 4) runs as three passes -- two 16-point register transforms of fft_lane.h and an
+//              R-point one -- with twiddle multiplications and an exchange through the wave's own LDS buffer
+//              between them (a wave's LDS operations execute in program order, so no workgroup barrier is
+//              needed), then the untangle into the M + 1 spectrum values, the sparse triangular filters
+//              (the frame's lanes share the filters and, when there are fewer filters than half the lanes,
+//              each filter's band), ln, DCT-II * lifter (one lane per coefficient);
 //   tile end   the static rows of the tile and its halo (2 * pad_fac frames on each side that
 //              continues) sit in LDS: delta over them, then delta of the deltas, both with the
 //              indices clamped to the utterance (np.pad(mode='edge'), mfcc-self5.py:174).
@@ -61,14 +61,10 @@ struct GeneralConst {
   int32_t lane16;         // 1: nfft <= 512, general16_kernel runs; tw then holds [512][2] exp(-2 pi i k / 512)
 };
 
-// dynamic LDS of the kernel, in floats: the twiddle table (nfft floats), the filter weights and
-// the DCT matrix when the plan found room for them (bankc_lds, dct_lds floats; not counted by
-// general_smem_bytes), per wave a complex FFT buffer, a spectrum row and a ln-mel row; per
-// workgroup the static and delta rows of a tile (MFCC-39 only)
-__host__ __device__ inline int general_row_floats(int nfft) { return (nfft / 2 + 1 + 3) & ~3; }
-__host__ __device__ inline int general_wave_floats(int nfft, int nmel) {
-  return nfft + general_row_floats(nfft) + ((nmel + 1 + 3) & ~3);
-}
+// dynamic LDS of the kernels, in floats: the twiddle table, the filters' band table, per wave the frames'
+// exchange buffers and ln-mel rows, the filter weights and the DCT matrix when the plan found room for them
+// (bankc_lds, dct_lds floats; not counted by general_smem_bytes); per workgroup the static and delta rows of
+// a tile (MFCC-39 only)
 // general16_kernel: the 512-point twiddle table (1024 floats), the filters' band table (3 ints per filter),
 // per wave four 2 KiB exchange buffers (the frames' spectrum rows afterwards) and four ln-mel rows
 __host__ __device__ inline int general16_lrow_floats(int nmel) { return (nmel + 1 + 3) & ~3; }
@@ -89,20 +85,6 @@ inline size_t general_fixed_floats(int nfft, int nmel) {
 }
 inline size_t general_smem_bytes(int nfft, int nmel, int numcep, int stat_rows) {
   return (general_fixed_floats(nfft, nmel) + (size_t)2 * stat_rows * numcep) * sizeof(float);
-}
-
-__device__ __forceinline__ unsigned bit_reverse(unsigned v, int bits) { return bits ? __brev(v) >> (32 - bits) : 0u; }
-
-// y[g] of utterance sample g (0 <= g < len): x[g] - c x[g-1], y[0] = x[0] (mfcc-self5.py:68).  int16
-// input: numpy works in float64, matched by a two-term coefficient and fused multiply-adds;
-// float32 input: numpy works in float32 with two roundings.
-template <typename T>
-__device__ __forceinline__ float preemph_at(const T* __restrict__ x, int64_t g, float pre_hi, float pre_lo) {
-  const float x0 = (float)x[g];
-  if (g == 0 || (pre_hi == 0.f && pre_lo == 0.f)) return x0;
-  const float x1 = (float)x[g - 1];
-  if (sizeof(T) == 2) return fmaf(-pre_lo, x1, fmaf(-pre_hi, x1, x0));
-  return __fsub_rn(x0, __fmul_rn(pre_hi, x1));
 }
 
 // Tile end of both kernels: delta (mfcc-self5.py:169-179) of rows d_lo .. d_hi-1 of the static rows in LDS,
@@ -137,196 +119,8 @@ __device__ __forceinline__ void general_tile_rows(const GeneralConst& gc, const 
   }
 }
 
-// TABLES_IN_LDS: the plan found room for the filter weights and the DCT matrix in LDS (both or
+// TABLES_IN_LDS (both kernels): the plan found room for the filter weights and the DCT matrix in LDS (both or
 // neither); a compile-time choice so that their reads are LDS or global instructions, not flat ones.
-template <typename T, bool TABLES_IN_LDS>
-__global__ void __launch_bounds__(256) general_kernel(const FusedParams p, const GeneralConst* __restrict__ gcp, int out_kind) {
-  extern __shared__ __attribute__((aligned(16))) float gsm[];
-  const GeneralConst gc = *gcp;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int M = gc.nfft >> 1, nbin = M + 1;
-  const int nmel = gc.nmel, ncep = gc.numcep, pf = gc.pad_fac;
-  const cf* const twl = (const cf*)gsm;                   // [M] exp(-2 pi i k / nfft): read by every butterfly, so kept in LDS
-  float* const tables = gsm + gc.nfft;                    // [bankc_lds] filter weights, [dct_lds] DCT * lifter
-  typedef const float __attribute__((address_space(3))) * lds_cptr;
-  typedef const float __attribute__((address_space(1))) * glb_cptr;
-  typedef typename std::conditional<TABLES_IN_LDS, lds_cptr, glb_cptr>::type tab_cptr;
-  const tab_cptr bankw = TABLES_IN_LDS ? (tab_cptr)(uintptr_t)(lds_cptr)tables : (tab_cptr)(uintptr_t)gc.bankc;
-  const tab_cptr dctw = TABLES_IN_LDS ? (tab_cptr)(uintptr_t)(lds_cptr)(tables + gc.bankc_lds) : (tab_cptr)(uintptr_t)gc.dctl;
-  float* const wbase = tables + gc.bankc_lds + gc.dct_lds + wave * general_wave_floats(gc.nfft, nmel);
-  cf* const z = (cf*)wbase;                               // [M] complex
-  float* const srow = wbase + gc.nfft;                    // [nbin] spectrum row
-  float* const lrow = srow + general_row_floats(gc.nfft); // [nmel] ln mel, then ln E
-  float* const stat = tables + gc.bankc_lds + gc.dct_lds + 4 * general_wave_floats(gc.nfft, nmel);  // [stat_rows][ncep]
-  float* const dlt = stat + gc.stat_rows * ncep;                     // [stat_rows][ncep]
-
-  const Tile tile = p.tiles[blockIdx.x];
-  const int64_t s_off = p.sample_off[tile.utt];
-  const int64_t len = p.sample_len ? p.sample_len[tile.utt] : p.sample_off[tile.utt + 1] - s_off;
-  const int64_t f_off = p.frame_off[tile.utt];
-  const int nframes = (int)(p.frame_off[tile.utt + 1] - f_off);
-  const int t0 = tile.t0, nt = tile.nt;
-  const bool full = out_kind == kOutMfcc39;
-  const int s_lo = full ? max(0, t0 - 2 * pf) : t0;
-  const int s_hi = full ? min(nframes, t0 + nt + 2 * pf) : t0 + nt;
-  const T* const x = (const T*)p.audio + s_off;
-  const int64_t ld = p.out_ld;
-  const bool mag = gc.spectrum != 0;
-
-  for (int i = tid; i < 2 * M; i += 256) gsm[i] = gc.tw[i];
-  for (int i = tid; i < gc.bankc_lds; i += 256) tables[i] = gc.bankc[i];  // the plan pads bankc to this length
-  for (int i = tid; i < gc.dct_lds; i += 256) tables[gc.bankc_lds + i] = i < nmel * ncep ? gc.dctl[i] : 0.f;
-  __syncthreads();
-  // band of this lane's filter(s): lane j and, beyond 64 filters, j + 64
-  int blo[2] = {0, 0}, bhi[2] = {0, 0}, boff[2] = {0, 0};
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-    if (lane + 64 * u < nmel) {
-      blo[u] = gc.band[3 * (lane + 64 * u)];
-      bhi[u] = gc.band[3 * (lane + 64 * u) + 1];
-      boff[u] = gc.band[3 * (lane + 64 * u) + 2];
-    }
-
-  for (int t = s_lo + wave; t < s_hi; t += 4) {
-    // ---- framing (mfcc-self5.py:85-95): samples t*step .. +frame_size, zeros past the utterance end
-    const int64_t g0 = (int64_t)t * gc.frame_step;
-    // Four complex points per lane and step, all their loads issued before the first is used (a load
-    // per point and a wait per point costs a memory round trip per 64 points).  Indices are clamped
-    // into the utterance so that every load is legal; what lies outside is zeroed below.
-    const bool pre_on = !(gc.pre_hi == 0.f && gc.pre_lo == 0.f);
-    for (int n0 = 0; n0 < M; n0 += 256) {
-      float xm[4], xa[4], xb[4], wa[4], wb[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t g = g0 + 2 * (n0 + 64 * u + lane);
-        const int64_t hi = len - 1;
-        xm[u] = (float)x[g - 1 < 0 ? 0 : (g - 1 > hi ? hi : g - 1)];
-        xa[u] = (float)x[g > hi ? hi : g];
-        xb[u] = (float)x[g + 1 > hi ? hi : g + 1];
-        wa[u] = wb[u] = 1.f;
-      }
-      if (gc.window) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = 2 * (n0 + 64 * u + lane);
-          wa[u] = gc.window[min(i, gc.frame_size - 1)];
-          wb[u] = gc.window[min(i + 1, gc.frame_size - 1)];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int n = n0 + 64 * u + lane;
-        if (n >= M) break;
-        const int i = 2 * n;
-        const int64_t g = g0 + i;
-        // y[0] = x[0], y[n] = x[n] - c x[n-1] (mfcc-self5.py:68), two-term coefficient for int16 samples
-        auto emph = [&](float cur, float prev, bool first) {
-          if (first || !pre_on) return cur;
-          if (sizeof(T) == 2) return fmaf(-gc.pre_lo, prev, fmaf(-gc.pre_hi, prev, cur));
-          return __fsub_rn(cur, __fmul_rn(gc.pre_hi, prev));
-        };
-        const float y0 = (i < gc.used && g < len) ? emph(xa[u], xm[u], g == 0) * wa[u] : 0.f;
-        const float y1 = (i + 1 < gc.used && g + 1 < len) ? emph(xb[u], xa[u], false) * wb[u] : 0.f;
-        z[bit_reverse((unsigned)n, gc.log2m)] = mk(y0, y1);
-      }
-    }
-    wave_sync();
-    // ---- nfft/2-point complex FFT, radix-2 decimation in time, in place
-    for (int s = 0; s < gc.log2m; ++s) {
-      const int half = 1 << s;
-      for (int j = lane; j < (M >> 1); j += 64) {
-        const int pos = j & (half - 1);
-        const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
-        const int k = pos << (gc.log2m - s);  // W_M^(pos M / (2 half)) = W_nfft^(pos M / half)
-        const cf w = twl[k];
-        const cf a = z[i0], b = z[i1];
-        const cf bw = mk(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
-        z[i0] = a + bw;
-        z[i1] = a - bw;
-      }
-      wave_sync();
-    }
-    // ---- untangle: X[k] = (A - i W^k B) / 2, A = Z[k] + conj Z[M-k], B = Z[k] - conj Z[M-k];
-    //      spectrum value |X|^2 / nfft or |X| (mfcc-self5.py:96-97)
-    float* const orow = (out_kind == kOutSpec || out_kind == kOutLogspec) && t >= t0 && t < t0 + nt ? p.out + (f_off + t) * ld : nullptr;
-    for (int k = lane; k <= M; k += 64) {
-      float p4;  // 4 |X[k]|^2
-      if (k == 0 || k == M) {
-        const cf z0 = z[0];
-        const float xr = k == 0 ? z0.x + z0.y : z0.x - z0.y;
-        p4 = 4.f * xr * xr;
-      } else {
-        const cf a = z[k], b = z[M - k];
-        const cf A = mk(a.x + b.x, a.y - b.y), B = mk(a.x - b.x, a.y + b.y);
-        const cf w = twl[k];
-        const cf C = mk(B.x * w.x - B.y * w.y, B.x * w.y + B.y * w.x);
-        const float ur = A.x + C.y, ui = A.y - C.x;  // A - i C
-        p4 = ur * ur + ui * ui;
-      }
-      const float v = mag ? 0.5f * sqrtf(p4) : p4 * (0.25f * gc.inv_nfft);
-      srow[k] = v;
-      if (orow) orow[k] = out_kind == kOutLogspec ? fast_ln(fmaxf(v, gc.log_floor)) : v;
-    }
-    wave_sync();
-    if (out_kind == kOutSpec || out_kind == kOutLogspec) continue;
-    // ---- mel energies and frame energy (mfcc-self5.py:119-134): ln of the unfloored band sums
-    //      (-inf on an empty band) unless floor_mel; ln E floored at the float64 epsilon
-    float e = 0.f;
-    for (int k = lane; k < nbin; k += 64) e += srow[k];
-    for (int m = 32; m >= 1; m >>= 1) e += __shfl_xor(e, m, 64);
-    if (e == 0.f) e = kEps64;
-    const float lne = fast_ln(e);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = lane + 64 * u;
-      if (j >= nmel) break;
-      const int lo = blo[u], hi = bhi[u];
-      const tab_cptr w = bankw + boff[u] - lo;  // w[k] = weight of bin k, lo <= k < hi
-      float acc = 0.f;
-      int k = lo;
-      for (; k + 4 <= hi; k += 4) {  // four weights in flight; the sum keeps the order of the bins
-        const float w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
-        acc = fmaf(srow[k], w0, acc);
-        acc = fmaf(srow[k + 1], w1, acc);
-        acc = fmaf(srow[k + 2], w2, acc);
-        acc = fmaf(srow[k + 3], w3, acc);
-      }
-      for (; k < hi; ++k) acc = fmaf(srow[k], w[k], acc);
-      if (gc.floor_mel && acc == 0.f) acc = kEps64;
-      lrow[j] = fast_ln(acc);
-    }
-    wave_sync();
-    const bool own = t >= t0 && t < t0 + nt;
-    if (out_kind == kOutLogmel) {
-      if (own) {
-        float* const o = p.out + (f_off + t) * ld;
-        for (int j = lane; j < nmel; j += 64) o[j] = lrow[j];
-        if (lane == 0) o[nmel] = lne;
-      }
-      wave_sync();
-      continue;
-    }
-    // ---- DCT-II * lifter, c0 := ln E (mfcc-self5.py:136-167)
-    for (int c = lane; c < ncep; c += 64) {
-      float acc = 0.f;
-      int n = 0;
-      for (; n + 4 <= nmel; n += 4) {
-        const float w0 = dctw[n * ncep + c], w1 = dctw[(n + 1) * ncep + c], w2 = dctw[(n + 2) * ncep + c], w3 = dctw[(n + 3) * ncep + c];
-        acc = fmaf(lrow[n], w0, acc);
-        acc = fmaf(lrow[n + 1], w1, acc);
-        acc = fmaf(lrow[n + 2], w2, acc);
-        acc = fmaf(lrow[n + 3], w3, acc);
-      }
-      for (; n < nmel; ++n) acc = fmaf(lrow[n], dctw[n * ncep + c], acc);
-      if (c == 0 && !gc.keep_c0) acc = lne;
-      if (full) stat[(t - s_lo) * ncep + c] = acc;
-      else if (own) p.out[(f_off + t) * ld + c] = acc;
-    }
-    wave_sync();
-  }
-  if (!full) return;
-  general_tile_rows(gc, stat, dlt, s_lo, t0, nt, nframes, p.out + f_off * ld, ld, tid);
-}
 
 // ---- FFT lengths up to 512: four frames per wave ------------------------------------------------------------
 template <typename T, bool TABLES_IN_LDS>
