@@ -156,6 +156,20 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
                  float* out, int64_t out_ld, int32_t out_kind, void* stream);
 int32_t mfcc_out_width(const mfcc_plan* plan, int32_t out_kind);
 
+/* mfcc_forward(MFCC_OUT_MFCC39) that collects, in the same launch, the statistics of a corpus normalisation over
+ * the rows it writes -- the constants mm, vv of (x + mm) .* vv, anal_recog_nn_liste.m:180, come from them -- so that
+ * no second pass reads the rows back: sums (float64[1 + 6 numcep] on the device, the layout mfcc_cmvn_accumulate
+ * keeps) gets sums[0] += total_frames, sums[1 + c] += sum of column c, sums[1 + 3 numcep + c] += sum of its squares.
+ * The rows are bit-identical to mfcc_forward's.  The writing lanes add their values to float32 column sums of their
+ * tile (at most 296 rows) in LDS; a second small kernel adds the tiles in float64.  The order of every addition is
+ * fixed by the code, so equal inputs give equal bits; against mfcc_cmvn_accumulate over the same rows (float64
+ * throughout) the sums differ by about 1e-7 relative.  workspace: device memory of mfcc_forward_sums_workspace()
+ * bytes, 4-byte aligned, written and read by this call only (calls that overlap in time need one each).
+ * Plans of the specialised kernel (mfcc_plan_kernel() == MFCC_KERNEL_AUTO); MFCC_ERR_UNSUPPORTED otherwise. */
+int64_t mfcc_forward_sums_workspace(const mfcc_plan* plan, const mfcc_layout* layout);
+int mfcc_forward_sums(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype,
+                      float* out, int64_t out_ld, double* sums, void* workspace, void* stream);
+
 /* The "257 coefficients x N frames" input of the MLP / CNN scripts (coeffs = 257, framenum = 17,
  * MLP_5hidlayer_40.py:244-248) straight from audio in one launch: winfft's spectrum rows
  * (mfcc-self5.py:96-99; their natural log for MFCC_OUT_LOGSPEC) stacked as padUtterance + slidingWin do

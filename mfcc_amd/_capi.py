@@ -76,6 +76,8 @@ SIGNATURES = {
     "mfcc_layout_info": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
     "mfcc_layout_offsets_host": (C.c_int, [_vp, _i64p, _i64p]),
     "mfcc_forward": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "mfcc_forward_sums_workspace": (_i64, [_vp, _vp]),
+    "mfcc_forward_sums": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
     "mfcc_out_width": (_i32, [_vp, _i32]),
     "mfcc_forward_stacked": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mfcc_preemphasis": (C.c_int, [_vp, _i32, _i64, _dbl, _vp, _vp]),

@@ -27,7 +27,7 @@ def _side_stream(dev):
 
 
 def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None, ddof=0, events=None, static_scratch=False,
-                     per_chunk_sums=False, overlap=False):
+                     per_chunk_sums=False, overlap=False, fused_sums=False):
     """fe: MFCC extractor; audio: this rank's packed device samples; lengths: its utterance
     lengths.  Returns (feats [sum F, D] normalised in place, sums float64[1 + 2 D] of the whole
     corpus, mm, vv).  ``events``: optional dict that receives per-phase lists of (start, end)
@@ -36,7 +36,9 @@ def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None,
     the caches) instead of in one pass after the last chunk.  ``overlap``: the same per-chunk accumulation on a
     second stream, ordered behind its chunk's extraction by an event, so that the memory-bound statistics pass
     runs beside the arithmetic-bound extraction of the next chunk; the sums are added chunk by chunk in chunk
-    order either way (equal inputs give equal bits)."""
+    order either way (equal inputs give equal bits).  ``fused_sums``: the extraction kernel itself adds up the rows it
+    writes (MFCC.forward_sums: float32 per tile, float64 across tiles, fixed order), so no pass reads the rows back for
+    the statistics; plans of the specialised kernel."""
     lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
     plan = fe.plan
     counts = np.array([plan.frames_for_length(int(n)) for n in lengths], dtype=np.int64) if len(set(lengths.tolist())) > 1 \
@@ -59,6 +61,9 @@ def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None,
         a.record()
         return b
 
+    if fused_sums and (overlap or per_chunk_sums):
+        raise ValueError("fused_sums replaces the statistics pass: not together with per_chunk_sums or overlap")
+    ws = None
     s_pos = f_pos = 0
     with torch.cuda.device(dev):
         main = torch.cuda.current_stream(dev)
@@ -71,7 +76,13 @@ def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None,
             lay = fe.layout(ls)
             view = out[f_pos:f_pos + nf]
             e = mark("forward")
-            fe.forward(audio[s_pos:s_pos + ns], lay, out=view)
+            if fused_sums:
+                need = fe.forward_sums_workspace(lay)
+                if ws is None or ws.numel() < need:
+                    ws = torch.empty(need, dtype=torch.float32, device=dev)
+                fe.forward_sums(audio[s_pos:s_pos + ns], lay, sums, out=view, workspace=ws)
+            else:
+                fe.forward(audio[s_pos:s_pos + ns], lay, out=view)
             if e: e.record()
             if side is not None:
                 side.wait_stream(main)  # behind this chunk's extraction; the next chunk's runs beside it
@@ -87,7 +98,7 @@ def corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=10000, out=None, group=None,
             f_pos += nf
         if side is not None:
             main.wait_stream(side)
-        elif not per_chunk_sums:
+        elif not per_chunk_sums and not fused_sums:
             # the rows are all resident: one pass over them (the extraction launches then run back to back)
             e = mark("accumulate")
             F.cmvn_accumulate(feats, sums, static=static_scratch)

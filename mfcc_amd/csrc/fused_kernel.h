@@ -132,6 +132,16 @@ constexpr int kDctFloats = kMelGroups * 64;
 // window are always one contiguous run of floats.
 constexpr int kORows = 64;
 constexpr int oring_floats(int ncep) { return (kORows + 20) * 3 * ncep; }
+// kOutMfcc39Sums: per wave, sums of c - K, delta-delta, delta and of the squares of c - K, delta, delta-delta,
+// 16 columns each (column q of block k at 16 k + q: the order in which the lanes' reduction leaves them); the
+// four waves' arrays are added in a fixed order when the tile is done.  K = the
+// static row of the tile's first frame (0 where that is not finite): the cepstra, c0 = ln E above all, have a
+// mean far from zero, and float32 sums of x^2 would lose the variance in it; delta rows have none.  A tile
+// leaves its 6 x 16 sums and the 16 values of K (kTileSums floats).
+constexpr int kTileSumCols = 6 * 16;
+constexpr int kTileSums = kTileSumCols + 16;
+static_assert(kTileSumCols == 6 * kMaxCep, "one column per coefficient a plan may have");
+constexpr int kSumsLdsFloats = 4 * kTileSumCols + 16;
 // ring_pitch = floats per ring row: numcep where it is a compile-time constant, else kMaxCep
 constexpr int smem_floats(int ring_pitch) { return kXbufFloats + kAbufFloats + ring_rows(ring_pitch) * ring_pitch + kTwFloats + kDctFloats; }
 // Stacked spectrum kinds: instead of the partial-DCT tiles and the statics ring, a ring of the last
@@ -150,6 +160,8 @@ static_assert(2 * (kStackMaxN / 2) + kBatch <= stack_ring_rows(kStackMaxN), "spe
 // gfx950 hands out LDS in units of 1280 bytes; three workgroups per CU fit while each takes at
 // most 42 units of the CU's 128.  The 13-coefficient kernels meet that exactly.
 static_assert(smem_floats(13) * 4 <= 42 * 1280 && smem_floats(kMaxCep) * 4 <= 42 * 1280, "LDS carve no longer allows three workgroups per CU");
+static_assert((smem_floats(13) + kSumsLdsFloats) * 4 <= 42 * 1280 && (smem_floats(kMaxCep) + kSumsLdsFloats) * 4 <= 42 * 1280,
+              "the column sums no longer fit beside the rest at three workgroups per CU");
 static_assert((kBatch - 1) * 512 + row_skew(kBatch - 1) + kRowPad <= kXbufFloats, "spectrum rows fit in the exchange buffer");
 
 constexpr float kEps64 = 2.220446049250313e-16f;     // np.finfo(float).eps, mfcc-self5.py:131
@@ -291,6 +303,7 @@ struct FusedParams {
   int64_t out_ld;
   const PlanConst* pc;
   int32_t stack_n;            // stacked kinds: frames per context window N (odd, <= kStackMaxN); out_ld = N * bins
+  float* tile_sums;           // kOutMfcc39Sums: [n_tiles][kTileSums] column sums of each tile's own rows
   StreamArgs stream;          // streaming kind only
 #ifdef MFCC_DIAG
   unsigned long long* dbg;    // [n_tiles][4 waves][8] cycle sums
@@ -328,7 +341,11 @@ enum : int { kOutMfcc39 = 0, kOutStatic = 1, kOutLogmel = 2, kOutSpec = 3, kOutL
              // MFCC-39 rows stacked over N frames, out[t, f * 3 ncep + j] = row[clamp(t + f - N / 2)][j] (padUtterance +
              // slidingWin with coeffs = 39, MLP_5hidlayer_40.py:70-105): the finished rows pass through a ring in
              // LDS, from which whole output rows are written
-             kOutMfcc39Stack = 8 };
+             kOutMfcc39Stack = 8,
+             // kOutMfcc39 that also sums the rows it writes and their squares per column (the statistics of a corpus
+             // normalisation, (x + mm) .* vv of anal_recog_nn_liste.m:180): every lane adds its three values of a row
+             // to its wave's column sums in LDS; a tile leaves 6 x 16 float sums in FusedParams::tile_sums
+             kOutMfcc39Sums = 9 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -507,7 +524,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const abuf = xbuf + kXbufFloats;
   // floats per row of the statics ring; only the MFCC-39 kind has one (the others would carry 2.5 KB
   // of LDS they never touch, one allocation unit too many for three workgroups per CU)
-  constexpr bool kRows39 = (OUT == kOutMfcc39 || OUT == kOutMfcc39Stack);  // kinds that form delta and delta-delta rows
+  constexpr bool kSums = OUT == kOutMfcc39Sums;
+  constexpr bool kRows39 = (OUT == kOutMfcc39 || OUT == kOutMfcc39Stack || kSums);  // kinds that form delta and delta-delta rows
   constexpr int RP = kRows39 ? (NCEP > 0 ? NCEP : kMaxCep) : 0;
   constexpr bool kStack = (OUT == kOutSpecStack || OUT == kOutLogspecStack);
   float* const ring = abuf + kAbufFloats;
@@ -518,6 +536,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   float* const twl = kStack ? sring + (srow_mask + 1) * kSRingPitch : ring + ring_rows(RP) * RP;
   float* const dctl = twl + kTwFloats;  // DCT * lifter weights (not in the stacked spectrum kinds' carve)
   float* const oring = dctl + kDctFloats;  // kOutMfcc39Stack: ring of finished rows
+  float* const csum = dctl + kDctFloats;   // kOutMfcc39Sums: [4 waves][kTileSumCols] column sums, then K[16]
+  float* const kpiv = csum + 4 * kTileSumCols;
 
   constexpr bool kSpecOut = (OUT == kOutSpec || OUT == kOutLogspec || kStack);
   constexpr bool kLogOut = (OUT == kOutLogspec || OUT == kOutLogspecStack);
@@ -556,7 +576,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   // frames this tile computes: its own, plus what the rows at its ends reach for where the utterance
   // continues (4 frames for delta-delta, half a context window for the stacked kinds)
   // (a stacked row also completes the 16-byte chunk it shares with the row before it: one frame back at least)
-  const int reach = (OUT == kOutMfcc39) ? kHalo : (OUT == kOutMfcc39Stack ? kHalo + (p.stack_n >> 1) : (kStack ? p.stack_n >> 1 : 0));
+  const int reach = (OUT == kOutMfcc39 || kSums) ? kHalo : (OUT == kOutMfcc39Stack ? kHalo + (p.stack_n >> 1) : (kStack ? p.stack_n >> 1 : 0));
   const int s_lo = (reach || kStack) ? max(0, t0 - max(reach, kStack ? 1 : 0)) : t0;
   const int s_hi = (reach || kStack) ? min(nframes, t0 + nt + reach) : t0 + nt;
   const int nmel = pc->nmel;
@@ -597,6 +617,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     const gfloat_ptr dwg = as_global(pc->dctW);
     for (int i = tid; i < kDctFloats; i += 256) dctl[i] = dwg[i];
   }
+  if (kSums)
+    for (int i = tid; i < kSumsLdsFloats; i += 256) csum[i] = 0.f;
   const cf* const twq = (const cf*)(twl + q * kTwPitch);
   const int partner_addr = ((lane & 48) | partner_lane(q)) << 2;
 
@@ -684,6 +706,44 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           om[ncep] = d[2];
           om[2 * ncep] = dd;
         }
+      }
+    } else if (kSums) {
+      // Column sums of the rows written.  Lane (g4, q) holds c, delta and delta-delta of row 4 wave + g4, column q:
+      // the four rows of lanes are added first -- v_permlane32_swap / v_permlane16_swap exchange half-waves and
+      // odd / even rows of two registers, so an exchange and an addition halve two values at once -- then the
+      // wave adds the totals to its own sums in LDS (plain read, add, write: an LDS float atomic costs three
+      // cycles per lane).  Columns >= numcep carry whatever the ring holds next to a row; nothing reads them.
+      const float dd = regress(d[0], d[1], d[2], d[3], d[4]);
+      const bool in = r >= t0 && r < t0 + nt;
+      if (q < ncep && in) {
+        float* const o = out_t0 + (r - t0) * ld + q;
+        o[0] = v[4];
+        o[ncep] = d[2];
+        o[2 * ncep] = dd;
+      }
+      if (r_wave + 3 >= t0 && r_wave < t0 + nt) {  // wave-uniform: some row of the wave belongs to the tile
+        float c = v[4] - kpiv[q], dl = d[2], d2 = dd;
+        if (r_wave < t0 || r_wave + 3 >= t0 + nt) {  // a tile's first or last rows: the others count as zero
+          c = in ? c : 0.f;
+          dl = in ? dl : 0.f;
+          d2 = in ? d2 : 0.f;
+        }
+        // (written as instructions: the compiler folds the sum of the builtin's two results into twice the first;
+        // a vector write of an operand has to be two wait states old when the exchange reads it)
+        auto fold32 = [](float a, float b) {  // rows [a0 + a2, a1 + a3, b0 + b2, b1 + b3]
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+          return a + b;
+        };
+        auto fold16 = [](float a, float b) {  // rows [a0 + a1, b0 + b1, a2 + a3, b2 + b3]
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+          return a + b;
+        };
+        const float x = fold32(c, dl), y = fold32(d2, c * c), z = fold32(dl * dl, d2 * d2);
+        const float r1 = fold16(x, y);  // rows: c, delta-delta, delta, c^2
+        const float r2 = fold16(z, z);  // rows: delta^2 (twice), delta-delta^2 (twice)
+        float* const cs = csum + wave * kTileSumCols;
+        cs[lane] += r1;
+        if (!(lane & 16)) cs[64 + 16 * (lane >> 5) + q] += r2;
       }
     } else if (q < ncep && r >= t0 && r < t0 + nt) {
       float* const o = out_t0 + (r - t0) * ld + q;
@@ -1165,14 +1225,17 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         unsigned info = slot_info[s];
         asm volatile("" : "+s"(info));
         MFCC_PHASE("7 filterbank slot (x23 per workgroup and batch, 5-6 per wave)");
+        // two accumulators: the dependency chain of the matrix instructions is half as long; a group's first
+        // slot starts them from the instruction's constant zero operand instead of eight register moves
         if (info & kSlotFirst) {
-          acc = f32x4{0.f, 0.f, 0.f, 0.f};
-          acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
           dwc = *(const f32x4*)__builtin_assume_aligned(dct_lane + 64 * ((info >> 17) & 15), 16);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][0], pa[s][0], zero, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][1], pa[s][1], zero, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][0], pa[s][0], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][1], pa[s][1], acc2, 0, 0, 0);
         }
-        // two accumulators: the dependency chain of the matrix instructions is half as long
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][0], pa[s][0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][1], pa[s][1], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][2], pa[s][2], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][3], pa[s][3], acc2, 0, 0, 0);
         if (info & kSlotLast) {
@@ -1261,6 +1324,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       if (q < ncep && t < s_hi) {
         if (kRows39) {
           const int rho = (t - s_lo + 8) & 31;
+          if (kSums && t == t0) kpiv[q] = __builtin_fabsf(v) < __builtin_inff() ? v : 0.f;  // the tile's pivot: read from the next batch on
           ring[rho * RP + q] = v;
           if (kMirror && rho < 8) ring[(rho + 32) * RP + q] = v;
         } else {
@@ -1308,6 +1372,13 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     if (OUT == kOutMfcc39Stack) {
       __syncthreads();
       write_stack_rows(o_hi);  // every row this tile's windows reach is in the ring now
+    }
+    if (kSums) {
+      __syncthreads();
+      if (tid < kTileSums)
+        p.tile_sums[(int64_t)blockIdx.x * kTileSums + tid] =
+            tid < kTileSumCols ? (csum[tid] + csum[kTileSumCols + tid]) + (csum[2 * kTileSumCols + tid] + csum[3 * kTileSumCols + tid])
+                               : kpiv[tid - kTileSumCols];
     }
   }
 #ifdef MFCC_DIAG

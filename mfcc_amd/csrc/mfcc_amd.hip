@@ -222,7 +222,7 @@ extern "C" void mfcc_debug_set_buffer(void* p) { g_dbg = (unsigned long long*)p;
 #endif
 
 // launch_fused selectors of the stacked spectrum kinds (not part of the public out_kind values)
-enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101, kLaunchStream = 102, kLaunchMfcc39Stack = 103 };
+enum : int32_t { kLaunchSpecStack = 100, kLaunchLogspecStack = 101, kLaunchStream = 102, kLaunchMfcc39Stack = 103, kLaunchMfcc39Sums = 104 };
 
 // The stacked-spectrum kernels use more dynamic LDS than a kernel may have without asking.  Asked once
 // per device, at plan creation (with that device current), so that a launch is nothing but a launch
@@ -292,11 +292,12 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
   }
   const bool c13 = plan->cfg.numcep == 13;
   // only the MFCC-39 kind keeps a ring of static rows in LDS: 13 floats per row where numcep is a compile-time 13
-  const bool rows39 = out_kind == MFCC_OUT_MFCC39 || out_kind == kLaunchMfcc39Stack;
+  const bool rows39 = out_kind == MFCC_OUT_MFCC39 || out_kind == kLaunchMfcc39Stack || out_kind == kLaunchMfcc39Sums;
   const int ring_pitch = rows39 ? (c13 ? 13 : mfcc::kMaxCep) : 0;
   const bool stacked = out_kind == kLaunchSpecStack || out_kind == kLaunchLogspecStack;
   const size_t smem = (stacked ? mfcc::smem_floats_stacked(fp.stack_n)
-                               : mfcc::smem_floats(ring_pitch) + (out_kind == kLaunchMfcc39Stack ? mfcc::oring_floats(plan->cfg.numcep) : 0)) *
+                               : mfcc::smem_floats(ring_pitch) + (out_kind == kLaunchMfcc39Stack ? mfcc::oring_floats(plan->cfg.numcep) : 0) +
+                                     (out_kind == kLaunchMfcc39Sums ? mfcc::kSumsLdsFloats : 0)) *
                           sizeof(float) + MFCC_EXTRA_SMEM;
   const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
   // (the stacked kinds take more than the 64 KiB of dynamic LDS a kernel gets without asking: allow_stacked_lds())
@@ -331,6 +332,10 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     case kLaunchMfcc39Stack:
       if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39Stack, 13);
       else MFCC_LAUNCH(mfcc::kOutMfcc39Stack, 0);
+      break;
+    case kLaunchMfcc39Sums:
+      if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39Sums, 13);
+      else MFCC_LAUNCH(mfcc::kOutMfcc39Sums, 0);
       break;
   }
 #undef MFCC_LAUNCH_G
@@ -936,8 +941,9 @@ int mfcc_layout_offsets_host(const mfcc_layout* l, int64_t* sample_offsets_host,
   return MFCC_OK;
 }
 
-int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype, float* out,
-                 int64_t out_ld, int32_t out_kind, void* stream) {
+// mfcc_forward; tile_sums != nullptr: the MFCC-39 kind that also leaves the column sums of every tile there
+static int forward_rows(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype, float* out,
+                        int64_t out_ld, int32_t out_kind, float* tile_sums, void* stream) {
   if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward: null plan or layout");
   if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
   if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_forward: the layout holds frame counts only (mfcc_layout_create_frames)");
@@ -976,11 +982,38 @@ int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* a
   }
   fp.pc = plan->pc;
   fp.stack_n = 0;
+  fp.tile_sums = tile_sums;
 #ifdef MFCC_DIAG
   fp.dbg = g_dbg;
 #endif
 
-  launch_fused(plan, fp, layout->n_tiles, out_kind, audio_dtype == MFCC_AUDIO_I16, (hipStream_t)stream);
+  launch_fused(plan, fp, layout->n_tiles, tile_sums ? kLaunchMfcc39Sums : out_kind, audio_dtype == MFCC_AUDIO_I16, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return MFCC_OK;
+}
+
+int mfcc_forward(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype, float* out,
+                 int64_t out_ld, int32_t out_kind, void* stream) {
+  return forward_rows(plan, layout, audio, audio_dtype, out, out_ld, out_kind, nullptr, stream);
+}
+
+int64_t mfcc_forward_sums_workspace(const mfcc_plan* plan, const mfcc_layout* layout) {
+  if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward_sums_workspace: null plan or layout");
+  if (plan->general) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_forward_sums: plans of the specialised kernel only; use mfcc_forward + mfcc_cmvn_accumulate");
+  return (int64_t)(layout->n_tiles > 0 ? layout->n_tiles : 1) * mfcc::kTileSums * (int64_t)sizeof(float);
+}
+
+int mfcc_forward_sums(const mfcc_plan* plan, const mfcc_layout* layout, const void* audio, int32_t audio_dtype, float* out,
+                      int64_t out_ld, double* sums, void* workspace, void* stream) {
+  if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward_sums: null plan or layout");
+  if (plan->general) return fail(MFCC_ERR_UNSUPPORTED, "mfcc_forward_sums: plans of the specialised kernel only; use mfcc_forward + mfcc_cmvn_accumulate");
+  if (!sums || !workspace) return fail(MFCC_ERR_INVALID, "mfcc_forward_sums: null sums or workspace");
+  if ((uintptr_t)workspace & 3) return fail(MFCC_ERR_INVALID, "mfcc_forward_sums: the workspace must be 4-byte aligned");
+  const int rc = forward_rows(plan, layout, audio, audio_dtype, out, out_ld, MFCC_OUT_MFCC39, (float*)workspace, stream);
+  if (rc) return rc;
+  if (layout->n_utts == 0 || layout->n_tiles == 0) return MFCC_OK;
+  hipLaunchKernelGGL(mfcc::tile_sums_finish_kernel, dim3(6 * plan->cfg.numcep), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                     (const mfcc::Tile*)layout->d_tiles, layout->n_tiles, (int)plan->cfg.numcep, layout->total_frames, sums);
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
 }
@@ -1023,6 +1056,7 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
   fp.total_elems = layout->total_samples;
   fp.pc = plan->pc;
   fp.stack_n = framenum;
+  fp.tile_sums = nullptr;
 #ifdef MFCC_DIAG
   fp.dbg = nullptr;
 #endif
@@ -1392,6 +1426,7 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
     fp.out_ld = mfcc::kMaxCep;
     fp.pc = plan->pc;
     fp.stack_n = 0;
+    fp.tile_sums = nullptr;
 #ifdef MFCC_DIAG
     fp.dbg = nullptr;
 #endif
@@ -1430,6 +1465,7 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
     fp.out_ld = mfcc::kMaxCep;
     fp.pc = plan->pc;
     fp.stack_n = 0;
+    fp.tile_sums = nullptr;
 #ifdef MFCC_DIAG
     fp.dbg = nullptr;
 #endif

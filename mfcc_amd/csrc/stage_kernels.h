@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fused_kernel.h"  // Tile, kTileSums
+
 namespace mfcc {
 
 constexpr float kEps64s = 2.220446049250313e-16f;
@@ -443,6 +445,38 @@ __global__ void __launch_bounds__(256) cmvn_finish_kernel(const double* __restri
   if (threadIdx.x == 0) {
     sums[1 + c] += red[0];
     if (c == 0) sums[0] += (double)n_rows;
+  }
+}
+
+// Second stage for the column sums the fused kernel leaves per tile (kOutMfcc39Sums): tile_sums is
+// [n_tiles][7][16] float -- blocks of 16 coefficients: sums of c - K, delta-delta, delta, then of the squares of
+// c - K, delta, delta-delta, then the tile's pivots K.  Workgroup (k, q), k = 0..2 the sums of c | delta |
+// delta-delta and 3..5 their squares, adds its column over the tiles in float64, in an order fixed by the code,
+// and puts the pivot back: sum x = S1 + n K, sum x^2 = S2 + 2 K S1 + n K^2.
+__global__ void __launch_bounds__(256) tile_sums_finish_kernel(const float* __restrict__ tile_sums, const Tile* __restrict__ tiles,
+                                                               int64_t n_tiles, int ncep, int64_t n_rows, double* __restrict__ sums) {
+  __shared__ double red[256];
+  const int k = blockIdx.x / ncep, q = blockIdx.x - k * ncep;  // k: 0..2 sums, 3..5 sums of squares
+  double a = 0.0;
+  for (int64_t b = threadIdx.x; b < n_tiles; b += 256) {
+    const float* const ts = tile_sums + b * kTileSums;
+    const int block = k == 1 ? 2 : (k == 2 ? 1 : k);  // the kernel leaves delta-delta before delta
+    double v = (double)ts[16 * block + q];
+    if (k == 0 || k == 3) {
+      const double piv = (double)ts[kTileSumCols + q], n = (double)tiles[b].nt;
+      v = k == 0 ? v + n * piv : v + 2.0 * piv * (double)ts[q] + n * piv * piv;
+    }
+    a += v;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int m = 128; m > 0; m >>= 1) {
+    if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[1 + k * ncep + q] += red[0];  // the 3 ncep sums, then the 3 ncep sums of squares
+    if (blockIdx.x == 0) sums[0] += (double)n_rows;
   }
 }
 

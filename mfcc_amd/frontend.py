@@ -306,6 +306,42 @@ class MFCC:
                                                 _OUT_KINDS[kind], _stream_ptr()))
         return out
 
+    def forward_sums(self, audio, layout, sums, out=None, workspace=None):
+        """MFCC-39 rows as forward() writes them, and in the same launch the statistics of a corpus normalisation:
+        sums (float64 device tensor [1 + 6 numcep], as cmvn_accumulate keeps it) += (rows, column sums, column
+        sums of squares) of the rows written.  The writer adds its values up in float32 per tile of at most 296
+        rows, the tiles are added in float64 in a fixed order: equal inputs give equal bits, and the sums agree
+        with cmvn_accumulate over the same rows to about 1e-7 relative.  Plans of the specialised kernel only.
+        ``workspace``: optional float32 device tensor that holds the per-tile sums (forward_sums_workspace()
+        floats); allocated when missing."""
+        if not audio.is_cuda or not audio.is_contiguous() or audio.dtype not in (torch.int16, torch.float32):
+            raise ValueError("audio must be a contiguous int16 or float32 device tensor")
+        if audio.numel() != layout.total_samples:
+            raise ValueError(f"audio has {audio.numel()} samples, layout expects {layout.total_samples}")
+        width = self.plan.out_width("mfcc39")
+        if sums.dtype != torch.float64 or not sums.is_cuda or not sums.is_contiguous() or sums.numel() != 1 + 2 * width:
+            raise ValueError(f"sums must be a contiguous float64 device tensor of {1 + 2 * width} elements")
+        if out is None:
+            out = torch.empty((layout.total_frames, width), dtype=torch.float32, device=audio.device)
+        elif (out.dtype != torch.float32 or not out.is_cuda or out.dim() != 2 or out.shape[0] != layout.total_frames
+              or out.shape[1] < width or out.stride(1) != 1):
+            raise ValueError("out must be a float32 device tensor [total_frames, >=width] with unit column stride")
+        lib = capi.load()
+        need = capi.check(lib.mfcc_forward_sums_workspace(self.plan._h, layout._h)) // 4
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.float32, device=audio.device)
+        elif workspace.dtype != torch.float32 or not workspace.is_cuda or not workspace.is_contiguous() or workspace.numel() < need:
+            raise ValueError(f"workspace must be a contiguous float32 device tensor of at least {need} elements")
+        code = capi.AUDIO_I16 if audio.dtype == torch.int16 else capi.AUDIO_F32
+        with _on(self.plan.device, audio, out):
+            capi.check(lib.mfcc_forward_sums(self.plan._h, layout._h, _ptr(audio), code, _ptr(out), out.stride(0), _ptr(sums),
+                                             _ptr(workspace), _stream_ptr()))
+        return out
+
+    def forward_sums_workspace(self, layout):
+        """float32 elements of the workspace forward_sums() needs for this layout"""
+        return capi.check(capi.load().mfcc_forward_sums_workspace(self.plan._h, layout._h)) // 4
+
     def _mfcc39_by_stages(self, audio, layout, out):
         """MFCC-39 for the rare plan whose delta rows do not fit the general kernel's LDS (mfcc_plan_supports):
         static rows in one launch, then delta and delta of delta per utterance (mfcc-self5.py:225-229)."""

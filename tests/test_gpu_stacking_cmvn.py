@@ -382,3 +382,65 @@ def test_corpus_pipeline_statistics_per_chunk_or_at_the_end(M):
         assert torch.equal(o[1], b[1]) and torch.equal(o[0], b[0])
     o = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=7, overlap=True, static_scratch=True)
     assert torch.equal(o[1], b[1]) and torch.equal(o[0], b[0])
+
+
+@pytest.mark.parametrize("variant,numcep,dtype", [("self5", 13, np.int16), ("self15", 13, np.float32), ("self5", 12, np.int16), ("self5", 16, np.int16)])
+def test_forward_sums_rows_and_statistics(M, variant, numcep, dtype):
+    """mfcc_forward_sums: rows bit-identical to mfcc_forward, the sums equal to a float64 reduction of those rows to
+    float32 rounding of a tile's partial sums, the same bits on every run, accumulation over calls; ragged batch with
+    one-frame utterances and tiles that end inside an utterance."""
+    rng = np.random.default_rng(123)
+    lengths = [400, 401, 1, 5000, 48000, 160 * 300 + 400, 7777, 560, 16000 * 7 + 13, 3000] + [int(v) for v in rng.integers(500, 60000, size=30)]
+    audios = [np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths]
+    packed = np.concatenate(audios)
+    audio = torch.from_numpy(packed if dtype == np.int16 else packed.astype(np.float32)).cuda()
+    fe = M.MFCC(variant, numcep=numcep)
+    lay = fe.layout(lengths)
+    d = 3 * numcep
+    ref_rows = fe.forward(audio, lay)
+    sums = torch.zeros(1 + 2 * d, dtype=torch.float64, device="cuda")
+    rows = fe.forward_sums(audio, lay, sums)
+    assert torch.equal(rows, ref_rows)
+    want = M.cmvn_accumulate(ref_rows).cpu().numpy()
+    got = sums.cpu().numpy()
+    assert got[0] == want[0] == lay.total_frames
+    # float32 partial sums of up to 296 values per tile: a few 1e-7 of the sum of the magnitudes
+    x = ref_rows.cpu().numpy().astype(np.float64)
+    mag = np.concatenate([np.abs(x).sum(0), (x * x).sum(0)])
+    assert np.all(np.abs(got[1:] - want[1:]) <= 2e-6 * mag + 1e-9), np.max(np.abs(got[1:] - want[1:]) / (mag + 1e-30))
+    again = torch.zeros_like(sums)
+    ws = torch.empty(fe.forward_sums_workspace(lay) + 5, dtype=torch.float32, device="cuda")
+    fe.forward_sums(audio, lay, again, out=torch.empty_like(rows), workspace=ws)
+    assert torch.equal(again, sums)
+    fe.forward_sums(audio, lay, again, workspace=ws)   # accumulates into what is there
+    assert np.allclose(again.cpu().numpy(), 2 * got, rtol=1e-15)
+    # normalisation constants from either set of sums: the same to float32 rounding
+    mm_a, vv_a = M.cmvn_constants(sums)
+    mm_b, vv_b = M.cmvn_constants(torch.from_numpy(want).cuda())
+    assert torch.allclose(mm_a, mm_b, rtol=1e-5, atol=1e-5) and torch.allclose(vv_a, vv_b, rtol=1e-5)
+
+
+def test_forward_sums_refusals_and_corpus_pipeline(M):
+    rng = np.random.default_rng(5)
+    lengths = [int(v) for v in rng.integers(1500, 9000, size=50)]
+    audio = torch.from_numpy(np.concatenate([np.clip(rng.standard_normal(n) * 3000, -32768, 32767).astype(np.int16) for n in lengths])).cuda()
+    fe = M.MFCC("self5")
+    a = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=7)
+    f = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=7, fused_sums=True)
+    g = M.corpus_mfcc_cmvn(fe, audio, lengths, chunk_utts=1000, fused_sums=True)
+    assert f[1][0] == a[1][0] == g[1][0]
+    assert np.allclose(f[1].cpu().numpy(), a[1].cpu().numpy(), rtol=3e-6, atol=1e-4)
+    assert (f[0] - a[0]).abs().max() < 1e-4 and (g[0] - a[0]).abs().max() < 1e-4
+    gen = M.MFCC("self5", kernel="general")
+    lay = gen.layout(lengths[:3])
+    with pytest.raises(RuntimeError):
+        gen.forward_sums(audio[:sum(lengths[:3])], lay, torch.zeros(79, dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        M.corpus_mfcc_cmvn(fe, audio, lengths, fused_sums=True, overlap=True)
+    # silence: ln 0 = -inf rows make the sums non-finite exactly as the two-pass route does
+    z = torch.zeros(4000, dtype=torch.int16, device="cuda")
+    lz = fe.layout([4000])
+    s1 = torch.zeros(79, dtype=torch.float64, device="cuda")
+    rz = fe.forward_sums(z, lz, s1)
+    s2 = M.cmvn_accumulate(rz)
+    assert torch.equal(torch.isfinite(s1), torch.isfinite(s2))
