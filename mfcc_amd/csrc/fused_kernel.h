@@ -1225,17 +1225,16 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         unsigned info = slot_info[s];
         asm volatile("" : "+s"(info));
         MFCC_PHASE("7 filterbank slot (x23 per workgroup and batch, 5-6 per wave)");
-        // two accumulators: the dependency chain of the matrix instructions is half as long; a group's first
-        // slot starts them from the instruction's constant zero operand instead of eight register moves
         if (info & kSlotFirst) {
-          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          // (starting the two chains from the instruction's constant zero operand in a branch of their own saves
+          // these eight moves and measures 1.5 % slower: 1.025 against 1.009 ms)
+          acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
           dwc = *(const f32x4*)__builtin_assume_aligned(dct_lane + 64 * ((info >> 17) & 15), 16);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][0], pa[s][0], zero, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][1], pa[s][1], zero, 0, 0, 0);
-        } else {
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][0], pa[s][0], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][1], pa[s][1], acc2, 0, 0, 0);
         }
+        // two accumulators: the dependency chain of the matrix instructions is half as long
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][0], pa[s][0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][1], pa[s][1], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][2], pa[s][2], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv[s][3], pa[s][3], acc2, 0, 0, 0);
         if (info & kSlotLast) {
