@@ -10,6 +10,7 @@ if [ "$MODE" = gpu ]; then
   bash tools/pmc.sh "$OUT/pmc"
   bash tools/pmc_stack.sh "$OUT/pmc_stack"
   timeout -k 10 300 python3 bench.py --config D > "$OUT/benchD.json" 2> "$OUT/benchD.err"
+  timeout -k 10 300 python3 bench.py --config D --two-pass-sums > "$OUT/benchD_two_pass.json" 2> "$OUT/benchD_two_pass.err"
   timeout -k 10 400 python3 tools/bench_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
   echo "gpu part done: run the collect step, then bench.py once more for the line with measured traffic"
 else
@@ -20,6 +21,7 @@ else
   python3 tools/pmc_summary.py "$OUT/pmc" "fused_kernel<0, 13, short" > profiles/${TAG}_pmc_summary.txt
   python3 tools/pmc_summary.py "$OUT/pmc_stack" "fused_kernel<6" > profiles/${TAG}_configC_hbm_counters.txt
   cp "$OUT/benchD.json" profiles/${TAG}_configD_bench.json
+  cp "$OUT/benchD_two_pass.json" profiles/${TAG}_configD_two_pass_bench.json
   cp "$OUT/configs.jsonl" profiles/${TAG}_configs.jsonl
   echo "collected into profiles/"
 fi
