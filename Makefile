@@ -22,6 +22,13 @@ variant: $(SRC) $(HDRS)
 	@mkdir -p build/variants
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -o build/variants/libmfcc_$(NAME).so $(SRC)
 
+# the experimental eight-wave kernel (mfcc_amd/csrc/split_kernel.h) as a library of its own, for
+# tools/split_check.py and tests/test_gpu_split_variant.py
+split: build/variants/libmfcc_split.so
+build/variants/libmfcc_split.so: $(SRC) $(HDRS)
+	@mkdir -p build/variants
+	$(HIPCC) $(HIPFLAGS) -DMFCC_USE_SPLIT -o $@ $(SRC)
+
 asm: $(SRC) $(HDRS)
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fno-signed-zeros -fno-slp-vectorize $(EXTRA) -S --cuda-device-only -o build/mfcc_amd.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
@@ -29,4 +36,4 @@ asm: $(SRC) $(HDRS)
 clean:
 	rm -rf mfcc_amd/lib build tests/host_sim/fft_sim
 
-.PHONY: all host_sim asm clean variant
+.PHONY: all host_sim asm clean variant split

@@ -304,6 +304,8 @@ struct FusedParams {
   const PlanConst* pc;
   int32_t stack_n;            // stacked kinds: frames per context window N (odd, <= kStackMaxN); out_ld = N * bins
   float* tile_sums;           // kOutMfcc39Sums: [n_tiles][kTileSums] column sums of each tile's own rows
+  const Tile* wg_tiles;       // split_kernel.h: the tiles of its persistent workgroups, workgroup after workgroup
+  const int32_t* wg_off;      //   [workgroups + 1] first tile of every workgroup in wg_tiles
   StreamArgs stream;          // streaming kind only
 #ifdef MFCC_DIAG
   unsigned long long* dbg;    // [n_tiles][4 waves][8] cycle sums
@@ -390,7 +392,8 @@ __device__ __forceinline__ float row_ror(float v) {
 // (stage_store), so that the HBM latency is covered by the matrix-core work in between.
 struct StageRegs {
   uint4 raw[3];   // chunks per thread: ceil((7 + 2800) / 8 / 256) = 2 for int16, 3 for float32
-  float prev[3];  // sample in front of each chunk
+  float prev[3];  // sample in front of each chunk: float32 input as it is, int16 input as the integer's bits (converted
+                  // by stage_store: a conversion here would make the loading code wait for its own loads)
   int delta;
 };
 
@@ -452,7 +455,9 @@ __device__ __forceinline__ void stage_load(const StageCtx<T>& c, StageRegs& r, i
   for (int k = 0; k < NR; ++k) {
     const int eb = batch_off * SZ + (int)min((unsigned)(tid + 256 * k), c.nchunk - 1) * 16;
     r.raw[k] = *(const uint4*)(base_b + (unsigned)min(eb, hi_b));
-    r.prev[k] = (float)*(const T*)(base_b - 16 + (unsigned)min(max(eb + 16 - SZ, front_b), last_b));
+    const T pv = *(const T*)(base_b - 16 + (unsigned)min(max(eb + 16 - SZ, front_b), last_b));
+    if (sizeof(T) == 2) r.prev[k] = __builtin_bit_cast(float, (int)pv);
+    else r.prev[k] = (float)pv;
   }
 }
 template <typename T, class G>
@@ -473,7 +478,7 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int
     if (c >= nchunk) break;
     const int e0 = c * CE;
     float x[CE + 1];
-    x[0] = r.prev[k];
+    x[0] = sizeof(T) == 2 ? (float)__builtin_bit_cast(int, r.prev[k]) : r.prev[k];
     const unsigned w[4] = {r.raw[k].x, r.raw[k].y, r.raw[k].z, r.raw[k].w};
     if (sizeof(T) == 2) {
 #pragma unroll

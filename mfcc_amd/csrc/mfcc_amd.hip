@@ -15,6 +15,9 @@
 
 #include "fused_kernel.h"
 #include "general_kernel.h"
+#ifdef MFCC_USE_SPLIT  // experimental build: MFCC-39 through the eight-wave kernel of split_kernel.h
+#include "split_kernel.h"
+#endif
 #include "stage_kernels.h"
 #include "stream_kernels.h"
 #include "tables.h"
@@ -186,6 +189,11 @@ struct mfcc_layout {
   int64_t* d_frame_off = nullptr;
   mfcc::Tile* d_tiles = nullptr;
   int64_t n_tiles;
+  // the same frames cut for the persistent workgroups of split_kernel.h: workgroup w walks
+  // d_wg_tiles[d_wg_off[w] .. d_wg_off[w + 1]); every workgroup gets about the same number of batches
+  mfcc::Tile* d_wg_tiles = nullptr;
+  int32_t* d_wg_off = nullptr;
+  int32_t n_wg = 0;
   bool frames_only = false;  // made by mfcc_layout_create_frames: frame offsets only, no audio geometry
   // what the tile list was cut for: a plan may only run on a layout of its own framing whose
   // tiles fit its kernel
@@ -253,13 +261,27 @@ static int allow_stacked_lds() {
   MFCC_ALLOW39(0, int16_t, mfcc::Geom8k);
   MFCC_ALLOW39(0, float, mfcc::Geom8k);
 #undef MFCC_ALLOW39
+#ifdef MFCC_USE_SPLIT
+  const int bytes_split = (int)(mfcc::split_smem_floats(mfcc::kMaxCep) * sizeof(float));
+#define MFCC_ALLOW_SPLIT(NCEP, T, G) \
+  HIP_TRY(hipFuncSetAttribute((const void*)mfcc::split_kernel<NCEP, T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_split))
+  MFCC_ALLOW_SPLIT(13, int16_t, mfcc::Geom16k);
+  MFCC_ALLOW_SPLIT(13, float, mfcc::Geom16k);
+  MFCC_ALLOW_SPLIT(13, int16_t, mfcc::Geom8k);
+  MFCC_ALLOW_SPLIT(13, float, mfcc::Geom8k);
+  MFCC_ALLOW_SPLIT(0, int16_t, mfcc::Geom16k);
+  MFCC_ALLOW_SPLIT(0, float, mfcc::Geom16k);
+  MFCC_ALLOW_SPLIT(0, int16_t, mfcc::Geom8k);
+  MFCC_ALLOW_SPLIT(0, float, mfcc::Geom8k);
+#undef MFCC_ALLOW_SPLIT
+#endif
   return MFCC_OK;
 }
 
 // One workgroup per tile; template arguments select the output kind, a compile-time numcep of 13
 // where it pays, and the sample type.
 static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int64_t n_tiles, int32_t out_kind, bool i16,
-                         hipStream_t st) {
+                         hipStream_t st, int32_t n_wg = 0) {
   const dim3 grid((unsigned)n_tiles), block(256);
   if (plan->general) {
     // the public out_kind values are the kernel's own
@@ -311,6 +333,23 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     if (g8k) MFCC_LAUNCH_G(OUT, NCEP, mfcc::Geom8k);           \
     else MFCC_LAUNCH_G(OUT, NCEP, mfcc::Geom16k);              \
   } while (0)
+#ifdef MFCC_USE_SPLIT
+  if (out_kind == MFCC_OUT_MFCC39 && n_wg > 0 && fp.wg_tiles) {
+    // eight waves per workgroup in two roles, two persistent workgroups per CU (split_kernel.h)
+    const size_t smem_s = mfcc::split_smem_floats(ring_pitch) * sizeof(float);
+    const dim3 block8(512);
+    const dim3 grid((unsigned)n_wg);
+#define MFCC_LAUNCH_S(NCEP, G)                                                                                 \
+  do {                                                                                                         \
+    if (i16) hipLaunchKernelGGL((mfcc::split_kernel<NCEP, int16_t, G>), grid, block8, smem_s, st, fp);         \
+    else hipLaunchKernelGGL((mfcc::split_kernel<NCEP, float, G>), grid, block8, smem_s, st, fp);               \
+  } while (0)
+    if (c13) { if (g8k) MFCC_LAUNCH_S(13, mfcc::Geom8k); else MFCC_LAUNCH_S(13, mfcc::Geom16k); }
+    else { if (g8k) MFCC_LAUNCH_S(0, mfcc::Geom8k); else MFCC_LAUNCH_S(0, mfcc::Geom16k); }
+#undef MFCC_LAUNCH_S
+    return;
+  }
+#endif
   switch (out_kind) {
     case MFCC_OUT_MFCC39:
       if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39, 13);
@@ -778,6 +817,66 @@ int32_t mfcc_out_width(const mfcc_plan* p, int32_t out_kind) {
   return fail(MFCC_ERR_INVALID, "out_kind=%d", out_kind);
 }
 
+#ifdef MFCC_USE_SPLIT
+// Tiles for the persistent workgroups of split_kernel.h.  A tile costs its batches (16 frames each, the halo
+// frames at the sides that continue included); the tiles are dealt out in order, n_wg workgroups, each up to
+// the same quota, and the tile that crosses a quota is cut at a batch boundary (its second part starts the next
+// workgroup's list; a cut costs the 8 halo frames both parts compute).
+static void split_schedule(const std::vector<mfcc::Tile>& tiles, const std::vector<int64_t>& frame_off, int n_wg,
+                           std::vector<mfcc::Tile>* out_tiles, std::vector<int32_t>* out_off) {
+  auto batches = [&](const mfcc::Tile& t) {
+    const int64_t nf = frame_off[(size_t)t.utt + 1] - frame_off[(size_t)t.utt];
+    const int64_t lo = std::max<int64_t>(0, (int64_t)t.t0 - mfcc::kHalo), hi = std::min<int64_t>(nf, (int64_t)t.t0 + t.nt + mfcc::kHalo);
+    return (hi - lo + mfcc::kBatch - 1) / mfcc::kBatch;
+  };
+  int64_t rest = 0;  // batches of the tiles not yet dealt out (those behind the current one)
+  for (const mfcc::Tile& t : tiles) rest += batches(t);
+  out_tiles->clear();
+  out_off->assign(1, 0);
+  int64_t have = 0, quota = 0;
+  // every workgroup's quota is its share of what is left, so that the batches the cuts add are spread too
+  auto open = [&](int64_t left_now) {
+    const int64_t wgs_left = n_wg - ((int64_t)out_off->size() - 1);
+    quota = std::max<int64_t>(1, (left_now + wgs_left - 1) / std::max<int64_t>(1, wgs_left));
+    have = 0;
+  };
+  auto close = [&](int64_t left_now) {
+    out_off->push_back((int32_t)out_tiles->size());
+    open(left_now);
+  };
+  open(rest);
+  for (size_t i = 0; i < tiles.size(); ++i) {
+    mfcc::Tile t = tiles[i];
+    rest -= batches(t);
+    for (;;) {
+      const bool last_wg = (int)out_off->size() == n_wg;  // the last workgroup takes what is left
+      const int64_t nbt = batches(t);
+      if (last_wg || have + nbt <= quota) {
+        out_tiles->push_back(t);
+        have += nbt;
+        if (!last_wg && have >= quota) close(rest);
+        break;
+      }
+      const int64_t room = quota - have;
+      const int64_t left = t.t0 > 0 ? mfcc::kHalo : 0;
+      const int64_t nt1 = room * mfcc::kBatch - left - mfcc::kHalo;  // its frames + both halos = room whole batches
+      if (room >= 2 && nt1 >= 1 && t.nt - nt1 >= mfcc::kBatch) {
+        out_tiles->push_back(mfcc::Tile{t.utt, t.t0, (int32_t)nt1, 0});
+        t = mfcc::Tile{t.utt, (int32_t)(t.t0 + nt1), (int32_t)(t.nt - nt1), 0};
+        close(rest + batches(t));
+      } else if (have > 0) {
+        close(rest + nbt);
+      } else {  // (cannot happen: an empty workgroup takes any tile; kept so that the loop always ends)
+        out_tiles->push_back(t);
+        close(rest);
+        break;
+      }
+    }
+  }
+  while ((int)out_off->size() < n_wg + 1) out_off->push_back((int32_t)out_tiles->size());
+}
+#endif
+
 static int layout_create_impl(const mfcc_plan* plan, const int64_t* lengths_host, int64_t n_utts, mfcc_layout** out) {
   if (!plan || !out || n_utts < 0 || (n_utts > 0 && !lengths_host)) return fail(MFCC_ERR_INVALID, "mfcc_layout_create: bad argument");
   if (n_utts > INT32_MAX) return fail(MFCC_ERR_UNSUPPORTED, "more than 2^31-1 utterances in one layout");
@@ -861,6 +960,21 @@ static int layout_create_impl(const mfcc_plan* plan, const int64_t* lengths_host
     mfcc_layout_destroy(l);
     return fail(MFCC_ERR_UNSUPPORTED, "layout needs more than 2^31-1 workgroups; split the batch");
   }
+#ifdef MFCC_USE_SPLIT
+  if (!rc && !plan->general && !tiles.empty()) {
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, plan->device) != hipSuccess || n_cu < 1) n_cu = 256;
+    // two eight-wave workgroups per CU (MFCC_DEBUG_WG_PER_CU: more, shorter lists for experiments)
+    const char* const dbg_wg = getenv("MFCC_DEBUG_WG_PER_CU");
+    const int per_cu = dbg_wg && atoi(dbg_wg) > 0 ? atoi(dbg_wg) : 2;
+    l->n_wg = (int32_t)std::min<int64_t>(per_cu * (int64_t)n_cu, l->n_tiles);
+    std::vector<mfcc::Tile> wg_tiles;
+    std::vector<int32_t> wg_off;
+    split_schedule(tiles, l->frame_off, l->n_wg, &wg_tiles, &wg_off);
+    rc = upload(wg_tiles, &l->d_wg_tiles);
+    if (!rc) rc = upload(wg_off, &l->d_wg_off);
+  }
+#endif
   if (!rc) rc = upload(l->sample_off, &l->d_sample_off);
   if (!rc) rc = upload(l->frame_off, &l->d_frame_off);
   if (!rc) rc = upload(tiles, &l->d_tiles);
@@ -922,6 +1036,8 @@ int mfcc_layout_destroy(mfcc_layout* l) {
   (void)hipFree(l->d_sample_off);
   (void)hipFree(l->d_frame_off);
   (void)hipFree(l->d_tiles);
+  (void)hipFree(l->d_wg_tiles);
+  (void)hipFree(l->d_wg_off);
   delete l;
   return MFCC_OK;
 }
@@ -983,11 +1099,14 @@ static int forward_rows(const mfcc_plan* plan, const mfcc_layout* layout, const 
   fp.pc = plan->pc;
   fp.stack_n = 0;
   fp.tile_sums = tile_sums;
+  fp.wg_tiles = layout->d_wg_tiles;
+  fp.wg_off = layout->d_wg_off;
 #ifdef MFCC_DIAG
   fp.dbg = g_dbg;
 #endif
 
-  launch_fused(plan, fp, layout->n_tiles, tile_sums ? kLaunchMfcc39Sums : out_kind, audio_dtype == MFCC_AUDIO_I16, (hipStream_t)stream);
+  launch_fused(plan, fp, layout->n_tiles, tile_sums ? kLaunchMfcc39Sums : out_kind, audio_dtype == MFCC_AUDIO_I16, (hipStream_t)stream,
+               layout->n_wg);
   HIP_TRY(hipGetLastError());
   return MFCC_OK;
 }
@@ -1057,6 +1176,8 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
   fp.pc = plan->pc;
   fp.stack_n = framenum;
   fp.tile_sums = nullptr;
+  fp.wg_tiles = nullptr;
+  fp.wg_off = nullptr;
 #ifdef MFCC_DIAG
   fp.dbg = nullptr;
 #endif
@@ -1427,6 +1548,8 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
     fp.pc = plan->pc;
     fp.stack_n = 0;
     fp.tile_sums = nullptr;
+    fp.wg_tiles = nullptr;
+    fp.wg_off = nullptr;
 #ifdef MFCC_DIAG
     fp.dbg = nullptr;
 #endif
@@ -1466,6 +1589,8 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
     fp.pc = plan->pc;
     fp.stack_n = 0;
     fp.tile_sums = nullptr;
+    fp.wg_tiles = nullptr;
+    fp.wg_off = nullptr;
 #ifdef MFCC_DIAG
     fp.dbg = nullptr;
 #endif
