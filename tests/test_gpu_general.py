@@ -292,3 +292,69 @@ def test_1024_and_2048_point_plans_against_the_oracle(M, fs, nfft, variant):
     static = O.staticfeatures(loge, O.dctopt(O.dct_ortho(logmel, 20, loop=False), 22))
     d = O.delta(static, 3, loop=False)
     assert_cep(got, O.spectrograms(static, d, O.delta(d, 3, loop=False)), f"fs={fs} hamming, 40 filters, 20 cepstra, pad_fac 3")
+
+
+def _oracle_rows(a, variant, fs, frame_time, step_time, num_bins, numcep, pad_fac, lift):
+    """MFCC rows of one utterance from the oracle's stage functions with free sizes (mfcc-self5.py:211-229 with
+    numcep, num_bins and pad_fac as arguments instead of the script's constants)."""
+    cfg = O.VARIANTS[variant]
+    sig = O.preemphasis(a, cfg["preemph"]) if cfg["preemph"] is not None else np.asarray(a)
+    mag, pw, _w, nfft = O.winfft(sig, fs, frame_time, step_time, loop=False)
+    spec = pw if cfg["spectrum"] == "power" else mag
+    logmel, loge = O.melspec(spec, O.melbanks(fs, num_bins, 0, nfft), loop=False)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        static = O.staticfeatures(loge, O.dctopt(O.dct_ortho(logmel, numcep, loop=False), lift))
+        d = O.delta(static, pad_fac, loop=False)
+        dd = O.delta(d, pad_fac, loop=False)
+    return spec, logmel, loge, O.spectrograms(static, d, dd)
+
+
+def test_random_configurations_against_the_oracle(M):
+    """A seeded sweep over what winfft, melbanks, mfcc and delta accept: sample rates 4 - 48 kHz, frame and step
+    times that give FFT lengths from 64 to 2048 points (all three kernels of the general path and, where the draw
+    hits 400/160 or 200/80, the specialised one), 8 - 64 filters, 2 - 24 cepstra, pad_fac 1 - 6, both variants, int16
+    and float32 samples, ragged batches with one-frame utterances: spectrum, ln-mel, ln E and MFCC rows of every
+    utterance against the oracle's stages."""
+    rng = np.random.default_rng(20240611)
+    seen = set()
+    for trial in range(28):
+        fs = float(rng.choice([4000, 8000, 11025, 16000, 22050, 32000, 44100, 48000]))
+        frame_time = float(rng.choice([8, 10, 16, 20, 25, 32, 40]))
+        step_time = float(rng.choice([4, 5, 8, 10, 12.5, 16]))
+        size, step, nfft = O.frame_geometry(fs, frame_time, step_time)
+        if size > 2048 or step > size or step < 1 or nfft < 64:
+            continue
+        num_bins = int(rng.integers(8, min(64, nfft // 8) + 1))
+        numcep = int(rng.integers(2, min(24, num_bins) + 1))
+        pad_fac = int(rng.integers(1, 7))
+        variant = VARIANTS[trial % 2]
+        lift = float(rng.choice([0, 22]))
+        lengths = [1, size, size + 1, int(rng.integers(size, 40 * size)), int(rng.integers(size, 80 * size)), 3 * step + size - 1]
+        audios = [_synth(9000 + 10 * trial + i, L) for i, L in enumerate(lengths)]
+        fe = M.MFCC(variant, fs=fs, frame_time=frame_time, step_time=step_time, num_bins=num_bins, numcep=numcep, pad_fac=pad_fac,
+                    lift_factor=lift)
+        assert (fe.plan.frame_size, fe.plan.frame_step, fe.plan.num_fft) == (size, step, nfft)
+        seen.add((nfft, bool(fe.plan.general)))
+        what = f"trial {trial}: fs={fs:g} {frame_time:g}/{step_time:g} ms -> {size}/{step}/{nfft}, {num_bins} filters, {numcep} cep, pad_fac {pad_fac}, {variant}"
+        packed = np.concatenate(audios)
+        as_float = trial % 3 == 2
+        t = torch.from_numpy(packed.astype(np.float32) if as_float else packed).cuda()
+        lay = fe.layout(lengths)
+        out = fe.forward(t, lay).cpu().numpy()
+        lm = fe.forward(t, lay, kind="logmel").cpu().numpy()
+        spec = fe.forward(t, lay, kind="spec").cpu().numpy()
+        for u, a in enumerate(audios):
+            r0, r1 = lay.frame_offsets[u], lay.frame_offsets[u + 1]
+            src = a.astype(np.float32) if as_float else a
+            sref, lmref, leref, oref = _oracle_rows(src, variant, fs, frame_time, step_time, num_bins, numcep, pad_fac, lift)
+            assert r1 - r0 == oref.shape[0] == O.frame_count(len(a), size, step), what
+            assert (np.abs(spec[r0:r1] - sref) <= 3e-6 * np.abs(sref).max(axis=1, keepdims=True) + 1e-30).all(), what
+            assert_logmel(lm[r0:r1, :num_bins], lmref, what + f" ln-mel L={len(a)}")
+            assert_logmel(lm[r0:r1, num_bins], leref, what + f" ln-E L={len(a)}")
+            # float32 samples: the reference would pre-emphasise in float32 too; cepstra to 2e-3 as in the other tests
+            assert_cep(out[r0:r1], oref, what + f" L={len(a)}", atol=2e-3 if as_float else CEP_ATOL_SWEEP)
+    # the draw reached every kernel of the general path
+    assert {n for n, g in seen if g} >= {1024, 2048} and any(n <= 512 for n, g in seen if g), sorted(seen)
+
+
+CEP_ATOL_SWEEP = 1e-3
