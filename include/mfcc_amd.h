@@ -47,7 +47,8 @@ extern "C" {
 
 /* Which kernel a plan runs.  AUTO takes the kernel specialised for the reference's own framings
  * (400/160 samples at 16 kHz with the 512-point FFT; 200/80 at 8 kHz with the 256-point FFT winfft
- * derives or an explicit 512-point one; pad_fac 2, <= 40 filters, <= 16 cepstra) when the
+ * derives or an explicit 512-point one; also 320/160 samples, frame_time = 20 at 16 kHz, for every
+ * entry point but mfcc_forward_stacked; pad_fac 2, <= 40 filters, <= 16 cepstra) when the
  * configuration fits it and the general one otherwise, which covers every other
  * (fs, frame_time, step_time) winfft accepts (mfcc-self5.py:75-84: frame sizes up to 2048 samples,
  * FFT lengths 2 .. 2048) and any pad_fac of delta (:169).  GENERAL forces the general kernel. */

@@ -72,6 +72,9 @@ struct FrameGeom {
 };
 typedef FrameGeom<400, 160> Geom16k;
 typedef FrameGeom<200, 80> Geom8k;
+// 20 ms frames every 10 ms at 16 kHz (frame_time = 20: int(16000 * 0.020) = 320 samples, mfcc-self5.py:75), FFT 512.
+// Instantiated for the kinds of mfcc_forward only (not for the stacked and streaming kinds).
+typedef FrameGeom<320, 160> Geom20ms;
 constexpr int kFrameSize = Geom16k::kSize;   // largest supported frame: sizes the LDS carve
 constexpr int kFrameStep = Geom16k::kStep;
 constexpr int kNfft = 512;        // next power of two, mfcc-self5.py:79-84
@@ -868,12 +871,17 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
             x[n1] = mk(0.f, 0.f);
           }
         }
-        static_assert(kFull == 12 || kFull == 6, "wait counts below are written for 400- and 200-sample frames");
+        static_assert(kFull == 12 || kFull == 10 || kFull == 6, "wait counts below are written for 400-, 320- and 200-sample frames");
         if (kFull == 12) {
           asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(x[0]), "+v"(x[4]), "+v"(x[8]));
           asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x[1]), "+v"(x[5]), "+v"(x[9]));
           asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(x[2]), "+v"(x[6]), "+v"(x[10]));
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[3]), "+v"(x[7]), "+v"(x[11]));
+        } else if (kFull == 10) {  // issued: 0 4 8 | 1 5 9 | 2 6 | 3 7
+          asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(x[0]), "+v"(x[4]), "+v"(x[8]));
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[1]), "+v"(x[5]), "+v"(x[9]));
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x[2]), "+v"(x[6]));
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[3]), "+v"(x[7]));
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
         }

@@ -169,6 +169,9 @@ struct mfcc_plan {
   float pre_hi, pre_lo, spec_scale;
   // general kernel (general_kernel.h): set when the configuration is outside the specialised kernel
   bool general = false;
+  // 320/160-sample frames (frame_time = 20 at 16 kHz): the specialised kernel, instantiated for the kinds of
+  // mfcc_forward only -- stacked rows take mfcc_forward + mfcc_stack_context, streams the three-launch form
+  bool plain_only = false;
   int32_t gen_nt_max = 0;  // output frames per tile
   bool gen_no_delta = false;  // no room in LDS for a tile's static / delta rows: every kind but MFCC-39
   size_t gen_smem = 0;     // dynamic LDS per workgroup
@@ -321,7 +324,7 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
                                : mfcc::smem_floats(ring_pitch) + (out_kind == kLaunchMfcc39Stack ? mfcc::oring_floats(plan->cfg.numcep) : 0) +
                                      (out_kind == kLaunchMfcc39Sums ? mfcc::kSumsLdsFloats : 0)) *
                           sizeof(float) + MFCC_EXTRA_SMEM;
-  const bool g8k = plan->frame_size == mfcc::Geom8k::kSize;
+  const bool g8k = plan->frame_size == mfcc::Geom8k::kSize, g20 = plan->frame_size == mfcc::Geom20ms::kSize;
   // (the stacked kinds take more than the 64 KiB of dynamic LDS a kernel gets without asking: allow_stacked_lds())
 #define MFCC_LAUNCH_G(OUT, NCEP, G)                                                                          \
   do {                                                                                                       \
@@ -333,8 +336,14 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
     if (g8k) MFCC_LAUNCH_G(OUT, NCEP, mfcc::Geom8k);           \
     else MFCC_LAUNCH_G(OUT, NCEP, mfcc::Geom16k);              \
   } while (0)
+  // the kinds of mfcc_forward also exist for 320/160-sample frames
+#define MFCC_LAUNCH3(OUT, NCEP)                                \
+  do {                                                         \
+    if (g20) MFCC_LAUNCH_G(OUT, NCEP, mfcc::Geom20ms);         \
+    else MFCC_LAUNCH(OUT, NCEP);                               \
+  } while (0)
 #ifdef MFCC_USE_SPLIT
-  if (out_kind == MFCC_OUT_MFCC39 && n_wg > 0 && fp.wg_tiles) {
+  if (out_kind == MFCC_OUT_MFCC39 && n_wg > 0 && fp.wg_tiles && !g20) {
     // eight waves per workgroup in two roles, two persistent workgroups per CU (split_kernel.h)
     const size_t smem_s = mfcc::split_smem_floats(ring_pitch) * sizeof(float);
     const dim3 block8(512);
@@ -352,16 +361,16 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
 #endif
   switch (out_kind) {
     case MFCC_OUT_MFCC39:
-      if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39, 13);
-      else MFCC_LAUNCH(mfcc::kOutMfcc39, 0);
+      if (c13) MFCC_LAUNCH3(mfcc::kOutMfcc39, 13);
+      else MFCC_LAUNCH3(mfcc::kOutMfcc39, 0);
       break;
     case MFCC_OUT_STATIC:
-      if (c13) MFCC_LAUNCH(mfcc::kOutStatic, 13);
-      else MFCC_LAUNCH(mfcc::kOutStatic, 0);
+      if (c13) MFCC_LAUNCH3(mfcc::kOutStatic, 13);
+      else MFCC_LAUNCH3(mfcc::kOutStatic, 0);
       break;
-    case MFCC_OUT_LOGMEL: MFCC_LAUNCH(mfcc::kOutLogmel, 0); break;
-    case MFCC_OUT_SPEC: MFCC_LAUNCH(mfcc::kOutSpec, 0); break;
-    case MFCC_OUT_LOGSPEC: MFCC_LAUNCH(mfcc::kOutLogspec, 0); break;
+    case MFCC_OUT_LOGMEL: MFCC_LAUNCH3(mfcc::kOutLogmel, 0); break;
+    case MFCC_OUT_SPEC: MFCC_LAUNCH3(mfcc::kOutSpec, 0); break;
+    case MFCC_OUT_LOGSPEC: MFCC_LAUNCH3(mfcc::kOutLogspec, 0); break;
     case kLaunchSpecStack: MFCC_LAUNCH(mfcc::kOutSpecStack, 0); break;
     case kLaunchLogspecStack: MFCC_LAUNCH(mfcc::kOutLogspecStack, 0); break;
     case kLaunchStream:
@@ -373,12 +382,13 @@ static void launch_fused(const mfcc_plan* plan, const mfcc::FusedParams& fp, int
       else MFCC_LAUNCH(mfcc::kOutMfcc39Stack, 0);
       break;
     case kLaunchMfcc39Sums:
-      if (c13) MFCC_LAUNCH(mfcc::kOutMfcc39Sums, 13);
-      else MFCC_LAUNCH(mfcc::kOutMfcc39Sums, 0);
+      if (c13) MFCC_LAUNCH3(mfcc::kOutMfcc39Sums, 13);
+      else MFCC_LAUNCH3(mfcc::kOutMfcc39Sums, 0);
       break;
   }
 #undef MFCC_LAUNCH_G
 #undef MFCC_LAUNCH
+#undef MFCC_LAUNCH3
 }
 
 // A layout's tile list was cut for the plan it was created with; another plan may use it when
@@ -744,8 +754,10 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
   const bool g16k = size == mfcc::Geom16k::kSize && step == mfcc::Geom16k::kStep;
   const bool g8k = size == mfcc::Geom8k::kSize && step == mfcc::Geom8k::kStep;
   // 512-point FFT, or the 256-point FFT winfft derives for 200-sample frames (taken from the even bins)
+  const bool g20 = size == mfcc::Geom20ms::kSize && step == mfcc::Geom20ms::kStep;  // frame_time = 20 at 16 kHz
   const bool fft_ok = nfft == mfcc::kNfft || (g8k && nfft == mfcc::kNfft / 2);
-  bool specialised = cfg->kernel == MFCC_KERNEL_AUTO && (g16k || g8k) && fft_ok && cfg->num_bins <= mfcc::kMaxMel &&
+  p->plain_only = g20;
+  bool specialised = cfg->kernel == MFCC_KERNEL_AUTO && (g16k || g8k || g20) && fft_ok && cfg->num_bins <= mfcc::kMaxMel &&
                      cfg->numcep <= mfcc::kMaxCep && cfg->pad_fac == 2 && !cfg->keep_c0;
   int rc = MFCC_OK;
   try {
@@ -753,6 +765,7 @@ int mfcc_plan_create(const mfcc_config* cfg, int device, mfcc_plan** out) {
       rc = build_specialised(p);
       if (rc == 1) { specialised = false; rc = MFCC_OK; }
     }
+    if (!specialised) p->plain_only = false;
     if (!specialised && !rc) rc = build_general(p);
     if (specialised && !rc) rc = allow_stacked_lds();
   } catch (const std::bad_alloc&) {
@@ -1143,10 +1156,10 @@ int mfcc_forward_stacked(const mfcc_plan* plan, const mfcc_layout* layout, const
   if (!plan || !layout) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: null plan or layout");
   if (plan->device != layout->device) return fail(MFCC_ERR_INVALID, "plan and layout live on different devices");
   if (layout->frames_only) return fail(MFCC_ERR_INVALID, "mfcc_forward_stacked: the layout holds frame counts only (mfcc_layout_create_frames)");
-  if (plan->general || (plan->nfft != mfcc::kNfft && out_kind != MFCC_OUT_MFCC39))
-    return fail(MFCC_ERR_UNSUPPORTED, "mfcc_forward_stacked: built for 512-point plans of the specialised kernel (this one: framing %d/%d, "
-                "%d-point FFT%s); use mfcc_forward + mfcc_stack_context", plan->frame_size, plan->frame_step, plan->nfft,
-                plan->general ? ", general kernel" : "");
+  if (plan->general || plan->plain_only || (plan->nfft != mfcc::kNfft && out_kind != MFCC_OUT_MFCC39))
+    return fail(MFCC_ERR_UNSUPPORTED, "mfcc_forward_stacked: built for 512-point plans of the specialised kernel with 400/160- or "
+                "200/80-sample frames (this one: framing %d/%d, %d-point FFT%s); use mfcc_forward + mfcc_stack_context",
+                plan->frame_size, plan->frame_step, plan->nfft, plan->general ? ", general kernel" : "");
   {
     const int rc_l = layout_fits(plan, layout);
     if (rc_l) return rc_l;
@@ -1535,7 +1548,7 @@ static int stream_step(mfcc_stream* s, const void* chunk, int64_t chunk_ld, int3
     s->f_done = f_target;
     s->e_done = e_target;
   };
-  if (!plan->general && ss.tiles_per_stream <= 1) {
+  if (!plan->general && !plan->plain_only && ss.tiles_per_stream <= 1) {
     // the usual push (new frames fit one tile): one launch, workgroup b = stream b, does all three parts
     mfcc::FusedParams fp;
     fp.audio = s->seg;

@@ -42,7 +42,8 @@ def test_other_frame_geometries_against_reference_goldens(M, golden, gname, vari
     assert (fe.plan.frame_size, fe.plan.frame_step, fe.plan.num_fft) == (size, step, nfft) and nfft == int(g[f"{gname}_nfft"])
     # 8 kHz: 200/80-sample frames are a framing of the specialised kernel, whose 512-point transform
     # holds the 256-point spectrum on its even bins; the other framings run the general kernel
-    assert fe.plan.general == (gname != "8k")
+    # (and 320/160-sample frames, frame_time = 20 at 16 kHz, are a third framing of the specialised kernel)
+    assert fe.plan.general == (gname not in ("8k", "16k_20ms"))
     packed = torch.from_numpy(np.concatenate(audios)).cuda()
     lay = fe.layout(lengths)
     out = fe.forward(packed, lay).cpu().numpy()
@@ -358,3 +359,55 @@ def test_random_configurations_against_the_oracle(M):
 
 
 CEP_ATOL_SWEEP = 1e-3
+
+
+def test_20ms_frames_on_the_specialised_kernel(M):
+    """frame_time = 20 at 16 kHz (320/160 samples, 512-point FFT) runs the specialised kernel for the kinds of
+    mfcc_forward: against the oracle on a ragged batch, with the statistics entry, float32 samples and a run-time numcep;
+    stacked rows are refused there (mfcc_forward + mfcc_stack_context serve them) and streams take the three-launch form."""
+    rng = np.random.default_rng(77)
+    lengths = [1, 319, 320, 321, 480, 5000, 48000, 160 * 301 + 320, 100000] + [int(v) for v in rng.integers(400, 70000, size=40)]
+    audios = [_synth(700 + i, L) for i, L in enumerate(lengths)]
+    packed = torch.from_numpy(np.concatenate(audios)).cuda()
+    for variant in VARIANTS:
+        fe = M.MFCC(variant, frame_time=20)
+        assert not fe.plan.general and (fe.plan.frame_size, fe.plan.frame_step, fe.plan.num_fft) == (320, 160, 512)
+        lay = fe.layout(lengths)
+        out = fe.forward(packed, lay).cpu().numpy()
+        lm = fe.forward(packed, lay, kind="logmel").cpu().numpy()
+        spec = fe.forward(packed, lay, kind="spec").cpu().numpy()
+        st = fe.forward(packed, lay, kind="static").cpu().numpy()
+        for u in range(0, len(lengths), 3):
+            r0, r1 = lay.frame_offsets[u], lay.frame_offsets[u + 1]
+            ref = O.mfcc39(audios[u], variant, frame_time=20, return_stages=True)
+            assert r1 - r0 == ref["out"].shape[0]
+            assert_cep(out[r0:r1], ref["out"], f"20 ms {variant} L={lengths[u]}")
+            assert_cep(st[r0:r1], ref["out"][:, :13], f"20 ms {variant} static L={lengths[u]}")
+            assert_logmel(lm[r0:r1, :26], ref["logmel"], f"20 ms {variant} ln-mel L={lengths[u]}")
+            assert_logmel(lm[r0:r1, 26], ref["loge"], f"20 ms {variant} ln-E L={lengths[u]}")
+            sref = ref["pow"] if variant == "self5" else ref["mag"]
+            assert (np.abs(spec[r0:r1] - sref) <= 2e-6 * np.abs(sref).max(axis=1, keepdims=True)).all()
+        gen = M.MFCC(variant, frame_time=20, kernel="general")
+        assert gen.plan.general
+        assert_cep(gen.forward(packed, gen.layout(lengths)).cpu().numpy(), out, f"20 ms {variant} general vs specialised", atol=2e-3)
+        sums = torch.zeros(79, dtype=torch.float64, device="cuda")
+        assert torch.equal(fe.forward_sums(packed, lay, sums), torch.from_numpy(out).cuda())
+        want = M.cmvn_accumulate(torch.from_numpy(out).cuda()).cpu().numpy()
+        assert sums[0].item() == want[0] and np.allclose(sums.cpu().numpy()[1:], want[1:], rtol=1e-4, atol=1e-2)
+        outf = fe(packed.to(torch.float32), lengths=lengths).cpu().numpy()
+        assert_cep(outf, out, f"20 ms {variant} float input", atol=2e-3 if variant == "self5" else 1e-3)
+    fe12 = M.MFCC("self5", frame_time=20, numcep=12)
+    o12 = np.asarray(fe12(audios[6]))
+    assert o12.shape[1] == 36 and not fe12.plan.general
+    assert_cep(o12[:, :12], O.mfcc39(audios[6], "self5", frame_time=20)[:, :12], "20 ms numcep 12")
+    fe = M.MFCC("self5", frame_time=20)
+    with pytest.raises(RuntimeError):
+        M.spectrum_stack(fe, packed, fe.layout(lengths), 9)
+    # streaming: pushes of uneven size, then the flush, equal the offline rows of the same audio
+    a = audios[7]
+    s = M.StreamingMFCC("self5", n_streams=2, max_chunk=4000, frame_time=20)
+    assert not s.plan.general
+    both = torch.from_numpy(np.stack([a, a[::-1].copy()])).cuda()
+    got = _stream_all(s, both, [1000, 37, 4000, 160, 3999]).cpu().numpy()
+    np.testing.assert_allclose(got[0], np.asarray(fe(a)), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got[1], np.asarray(fe(a[::-1].copy())), rtol=0, atol=2e-5)

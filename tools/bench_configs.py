@@ -76,7 +76,8 @@ def config_general(args):
                          ("fs=8000 -> 200/80 samples, 256-point FFT (specialised kernel, even bins of its 512-point transform), 6 s utterances", dict(fs=8000), 8000),
                          ("general kernel forced, fs=8000 -> 200/80/256", dict(fs=8000, kernel="general"), 8000),
                          ("general kernel, pad_fac=3", dict(pad_fac=3), 16000),
-                         ("general kernel, frame_time=20 -> 320/160/512", dict(frame_time=20), 16000),
+                         ("frame_time=20 -> 320/160/512 (specialised kernel, third geometry)", dict(frame_time=20), 16000),
+                         ("general kernel forced, frame_time=20 -> 320/160/512", dict(frame_time=20, kernel="general"), 16000),
                          ("general kernel, fs=44100 -> 1102/441/2048 (64 lanes per frame)", dict(fs=44100), 44100),
                          ("general kernel, fs=22050 -> 551/220/1024 (32 lanes per frame)", dict(fs=22050), 22050)):
         fe = mfcc_amd.MFCC("self5", **kw)
