@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         auto write_chunks = [&](auto interior_tag, auto half_tag) {
           constexpr bool kInterior = decltype(interior_tag)::value;
           constexpr bool kHalf = decltype(half_tag)::value;
-          constexpr int U = 4;
+          constexpr int U = 4;  // (2, 6 and 8 measure the same: 9.87 - 9.94 ms for the 52 GB of config C)
           for (int ch0 = 0; ch0 <= ch_hi; ch0 += 64 * U) {
             f32x4_t v[U];
             bool across[U];
