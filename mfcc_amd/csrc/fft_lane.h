@@ -45,6 +45,8 @@ MFCC_HD cf operator*(cf a, cf b) { return cf{a.x * b.x, a.y * b.y}; }
 constexpr float kC1 = 0.92387953251128674f;  // cos(pi/8)
 constexpr float kS1 = 0.38268343236508977f;  // sin(pi/8)
 constexpr float kR2 = 0.70710678118654752f;  // sqrt(1/2)
+constexpr float kT1 = 0.41421356237309505f;  // tan(pi/8) = kS1 / kC1
+constexpr float kT3 = 2.41421356237309505f;  // tan(3 pi/8) = kC1 / kS1
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // a + (-i) b = (a.x + b.y, a.y - b.x)
@@ -116,6 +118,46 @@ __device__ __forceinline__ cf pair_y(cf a, cf b) {
   asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// a + k p, a - k p: k wave-uniform, the same factor for both halves (a scalar register pair (k, k))
+__device__ __forceinline__ cf fmak(cf p, cf k, cf a) {
+  cf d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(p), "s"(k), "v"(a));
+  return d;
+}
+__device__ __forceinline__ cf fmak_neg(cf p, cf k, cf a) {
+  cf d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(p), "s"(k), "v"(a));
+  return d;
+}
+// a + k (-i p) = (a.x + k p.y, a.y - k p.x)
+__device__ __forceinline__ cf fmak_mi(cf p, cf k, cf a) {
+  cf d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(p), "s"(k), "v"(a));
+  return d;
+}
+// a + k (i p) = (a.x - k p.y, a.y + k p.x)
+__device__ __forceinline__ cf fmak_pi(cf p, cf k, cf a) {
+  cf d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(p), "s"(k), "v"(a));
+  return d;
+}
+// One untangle step with the twiddle W512^k = c (1 - i t) given as tc = (t, c) = (tan, cos)(2 pi k / 512):
+// see untangle_power_tc below.  C' = B (1 - i t); X = (A.x + c C'.y, A.x - c C'.y); Y = (A.y - c C'.x, A.y + c C'.x)
+__device__ __forceinline__ cf unt_rot(cf b, cf tc) {
+  cf d;
+  asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(b), "v"(tc));
+  return d;
+}
+__device__ __forceinline__ cf unt_x(cf a, cf c, cf tc) {
+  cf d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(c), "v"(tc), "v"(a));
+  return d;
+}
+__device__ __forceinline__ cf unt_y(cf a, cf c, cf tc) {
+  cf d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(c), "v"(tc), "v"(a));
+  return d;
+}
 // |a|^2
 __device__ __forceinline__ float norm2(cf a) {
   const cf t = a * a;
@@ -132,6 +174,13 @@ MFCC_HD cf cmulk(cf a, cf w) { return cmul(a, w); }
 MFCC_HD void cmul2(cf& a0, cf w0, cf& a1, cf w1) { a0 = cmul(a0, w0); a1 = cmul(a1, w1); }
 MFCC_HD cf pair_x(cf a, cf b) { return mk(a.x + b.y, a.x - b.y); }
 MFCC_HD cf pair_y(cf a, cf b) { return mk(a.y - b.x, a.y + b.x); }
+MFCC_HD cf fmak(cf p, cf k, cf a) { return mk(a.x + k.x * p.x, a.y + k.y * p.y); }
+MFCC_HD cf fmak_neg(cf p, cf k, cf a) { return mk(a.x - k.x * p.x, a.y - k.y * p.y); }
+MFCC_HD cf fmak_mi(cf p, cf k, cf a) { return mk(a.x + k.x * p.y, a.y - k.y * p.x); }
+MFCC_HD cf fmak_pi(cf p, cf k, cf a) { return mk(a.x - k.x * p.y, a.y + k.y * p.x); }
+MFCC_HD cf unt_rot(cf b, cf tc) { return mk(b.x + tc.x * b.y, b.y - tc.x * b.x); }
+MFCC_HD cf unt_x(cf a, cf c, cf tc) { return mk(a.x + tc.y * c.y, a.x - tc.y * c.y); }
+MFCC_HD cf unt_y(cf a, cf c, cf tc) { return mk(a.y - tc.y * c.x, a.y + tc.y * c.x); }
 MFCC_HD float norm2(cf a) { return a.x * a.x + a.y * a.y; }
 #endif
 
@@ -147,8 +196,7 @@ MFCC_HD void radix4(cf& a0, cf& a1, cf& a2, cf& a3) {
 
 // 16-point forward DFT, natural order in and out, all indices compile-time.
 // x[n], n = 4a + b;  X[c + 4d] = sum_b W4^(bd) W16^(bc) sum_a x[4a+b] W4^(ac).
-// Split in three parts so that a caller can slot independent work (matrix-core
-// instructions of another product) between them; fft16 = a, b, c.
+// Two halves: the radix-4 butterflies over a (fft16_a), then twiddles and butterflies over b (fft16_bc).
 MFCC_HD void fft16_a(cf (&x)[16]) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) radix4(x[b], x[4 + b], x[8 + b], x[12 + b]);
@@ -182,21 +230,45 @@ MFCC_HD void fft16_a_pruned(cf (&x)[16]) {
     }
   }
 }
-MFCC_HD void fft16_b(cf (&x)[16]) {
-  // after the first pass x[4c + b] holds Y_b[c]; twiddle by W16^(bc), W16^m = (cos, -sin)(2 pi m / 16)
-  x[4 + 1] = cmulk(x[4 + 1], mk(kC1, -kS1));     // b=1 c=1  m=1
-  x[8 + 1] = cmulk(x[8 + 1], mk(kR2, -kR2));     // b=1 c=2  m=2
-  x[12 + 1] = cmulk(x[12 + 1], mk(kS1, -kC1));   // b=1 c=3  m=3
-  x[4 + 2] = cmulk(x[4 + 2], mk(kR2, -kR2));     // b=2 c=1  m=2
-  x[8 + 2] = mul_mi(x[8 + 2]);                   // b=2 c=2  m=4
-  x[12 + 2] = cmulk(x[12 + 2], mk(-kR2, -kR2));  // b=2 c=3  m=6
-  x[4 + 3] = cmulk(x[4 + 3], mk(kS1, -kC1));     // b=3 c=1  m=3
-  x[8 + 3] = cmulk(x[8 + 3], mk(-kR2, -kR2));    // b=3 c=2  m=6
-  x[12 + 3] = cmulk(x[12 + 3], mk(-kC1, kS1));   // b=3 c=3  m=9
-}
-MFCC_HD void fft16_c(cf (&x)[16]) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) radix4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+// Second half of the 16-point transform: after the first pass x[4c + b] holds Y_b[c]; what follows is the
+// twiddle W16^(bc) and a radix-4 butterfly over b for every c.  A twiddle W16^m = C_m (1 - i T_m) (C = cos,
+// T = tan of pi m / 8) is applied as the rotation u (1 - i T) -- one packed fma -- and its scale C_m rides on
+// the packed fma that consumes the value in the butterfly, so a twiddled input costs one instruction instead
+// of the two of a complex product; for m = 2, 4, 6 (T = +-1 or a pure -i) the rotation is a packed add:
+//   c = 1:  W^1 = C1 (1 - i T1), W^2 = R2 (1 - i),  W^3 = S1 (1 - i T3)      S1 / C1 = T1
+//   c = 2:  W^2 = R2 (1 - i),    W^4 = -i,          W^6 = -R2 (1 + i)
+//   c = 3:  W^3 = S1 (1 - i T3), W^6 = -R2 (1 + i), W^9 = -C1 (1 - i T1)     C1 / S1 = T3
+// 40 packed instructions against 47 for nine complex products and four butterflies.
+MFCC_HD void fft16_bc(cf (&x)[16]) {
+  const cf c1 = mk(kC1, kC1), s1 = mk(kS1, kS1), r2 = mk(kR2, kR2), t1 = mk(kT1, kT1), t3 = mk(kT3, kT3);
+  radix4(x[0], x[1], x[2], x[3]);
+  {  // c = 1
+    const cf p1 = fmak_mi(x[5], t1, x[5]), p2 = add_mi(x[6], x[6]), p3 = fmak_mi(x[7], t3, x[7]);
+    const cf u0 = fmak(p2, r2, x[4]), u1 = fmak_neg(p2, r2, x[4]);
+    const cf u2 = fmak(p3, t1, p1), u3 = fmak_neg(p3, t1, p1);  // (a1 + a3) / C1, (a1 - a3) / C1
+    x[4] = fmak(u2, c1, u0);
+    x[6] = fmak_neg(u2, c1, u0);
+    x[5] = fmak_mi(u3, c1, u1);
+    x[7] = fmak_pi(u3, c1, u1);
+  }
+  {  // c = 2
+    const cf p1 = add_mi(x[9], x[9]), p3 = sub_mi(x[11], x[11]);
+    const cf u0 = add_mi(x[8], x[10]), u1 = sub_mi(x[8], x[10]);
+    const cf u2 = p1 - p3, u3 = p1 + p3;  // (a1 + a3) / R2, (a1 - a3) / R2: a3 = -R2 p3
+    x[8] = fmak(u2, r2, u0);
+    x[10] = fmak_neg(u2, r2, u0);
+    x[9] = fmak_mi(u3, r2, u1);
+    x[11] = fmak_pi(u3, r2, u1);
+  }
+  {  // c = 3
+    const cf p1 = fmak_mi(x[13], t3, x[13]), p2 = sub_mi(x[14], x[14]), p3 = fmak_mi(x[15], t1, x[15]);
+    const cf u0 = fmak_neg(p2, r2, x[12]), u1 = fmak(p2, r2, x[12]);  // a2 = -R2 p2
+    const cf u2 = fmak_neg(p3, t3, p1), u3 = fmak(p3, t3, p1);  // (a1 + a3) / S1, (a1 - a3) / S1: a3 = -C1 p3
+    x[12] = fmak(u2, s1, u0);
+    x[14] = fmak_neg(u2, s1, u0);
+    x[13] = fmak_mi(u3, s1, u1);
+    x[15] = fmak_pi(u3, s1, u1);
+  }
   // x[4c + d] now holds X[c + 4d]: transpose the 4x4 index grid (register renaming only)
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -209,14 +281,12 @@ MFCC_HD void fft16_c(cf (&x)[16]) {
 }
 MFCC_HD void fft16(cf (&x)[16]) {
   fft16_a(x);
-  fft16_b(x);
-  fft16_c(x);
+  fft16_bc(x);
 }
 template <int NZ>
 MFCC_HD void fft16_pruned(cf (&x)[16]) {
   fft16_a_pruned<NZ>(x);
-  fft16_b(x);
-  fft16_c(x);
+  fft16_bc(x);
 }
 
 // Position (in complex elements) of Y[k1][n2] inside one frame's 256-element exchange
@@ -238,6 +308,24 @@ MFCC_HD void untangle_power(cf a, cf b, cf w, float& p_lo, float& p_hi) {
   // U = A - iC, V = A + iC held as X = (U.x, V.x), Y = (U.y, V.y): both squared moduli come out
   // of one packed multiply and one packed fma
   const cf X = pair_x(A, C), Y = pair_y(A, C);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const cf p = __builtin_elementwise_fma(Y, Y, X * X);
+#else
+  const cf p = mk(X.x * X.x + Y.x * Y.x, X.y * X.y + Y.y * Y.y);
+#endif
+  p_lo = p.x;
+  p_hi = p.y;
+}
+
+
+// The same step with the twiddle W512^k = c (1 - i t) given as tc = (t, c) = (tan, cos)(2 pi k / 512), k < 128:
+// C' = B (1 - i t) is one packed fma and the factor c rides on the two fmas that form X and Y, seven packed
+// instructions instead of eight.  (tan stays below 82 for k <= 127; the products c * (t * B) round like W * B.)
+MFCC_HD void untangle_power_tc(cf a, cf b, cf tc, float& p_lo, float& p_hi) {
+  const cf A = add_conj(a, b);
+  const cf B = sub_conj(a, b);
+  const cf C = unt_rot(B, tc);
+  const cf X = unt_x(A, C, tc), Y = unt_y(A, C, tc);
 #if defined(__HIP_DEVICE_COMPILE__)
   const cf p = __builtin_elementwise_fma(Y, Y, X * X);
 #else

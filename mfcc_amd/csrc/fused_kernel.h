@@ -610,13 +610,13 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const gfloat4_ptr melW4 = (gfloat4_ptr)(uintptr_t)pc->melW + (wave * kMelQuads) * 16 + (lane & 15);
 
   // Twiddles per lane index q: stage 1 uses W256^(q k1) = W512^(2 q k1), k1 = 1..15, the
-  // untangle W512^(q + 16 s), s = 0..7.  They live in LDS (row q, 23 complex values) and are
+  // untangle W512^(q + 16 s), s = 0..7, as (tan, cos) pairs.  They live in LDS (row q, 23 pairs) and are
   // read when needed: 46 registers per lane would cost a wave of occupancy.
   {
     const gfloat_ptr tw = as_global(pc->tw512);
     for (int i = tid; i < 16 * 23; i += 256) {
       const int qq = i / 23, k = i - qq * 23;
-      const int m = k < 15 ? (2 * qq * (k + 1)) & 511 : qq + 16 * (k - 15);
+      const int m = k < 15 ? (2 * qq * (k + 1)) & 511 : 512 + qq + 16 * (k - 15);  // untangle entries: (tan, cos), behind the 512 powers
       const int slot = k < 15 ? kTwSt1 + k : kTwUnt + (k - 15);
       *(cf*)(twl + qq * kTwPitch + 2 * slot) = mk(tw[2 * m], tw[2 * m + 1]);
     }
@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           if (q == 0) pb[s] = x[(16 - h - s) & 15];  // lane 0 pairs inside itself: Z[16 s] with Z[16 (16 - s)]
           float lo, hi;
 #ifndef MFCC_ABL_UNT
-          untangle_power(x[h + s], pb[s], pw[s], lo, hi);
+          untangle_power_tc(x[h + s], pb[s], pw[s], lo, hi);
 #else
           lo = x[h + s].x + pb[s].x + pw[s].x; hi = x[h + s].y + pb[s].y + pw[s].y;
 #endif

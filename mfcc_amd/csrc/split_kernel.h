@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(512, 4) split_kernel(const FusedParams p) {
     const gfloat_ptr tw = as_global(pc->tw512);
     for (int i = tid; i < 16 * 23; i += 512) {
       const int qq = i / 23, k = i - qq * 23;
-      const int m = k < 15 ? (2 * qq * (k + 1)) & 511 : qq + 16 * (k - 15);
+      const int m = k < 15 ? (2 * qq * (k + 1)) & 511 : 512 + qq + 16 * (k - 15);  // untangle entries: (tan, cos), behind the 512 powers
       const int slot = k < 15 ? kTwSt1 + k : kTwUnt + (k - 15);
       *(cf*)(twl + qq * kTwPitch + 2 * slot) = mk(tw[2 * m], tw[2 * m + 1]);
     }
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(512, 4) split_kernel(const FusedParams p) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             if (q == 0) pb[s] = x[(16 - h - s) & 15];
-            untangle_power(x[h + s], pb[s], pw[s], lo4[s], hi4[s]);
+            untangle_power_tc(x[h + s], pb[s], pw[s], lo4[s], hi4[s]);
           }
           if (mag) {
             asm volatile("" ::: "memory");

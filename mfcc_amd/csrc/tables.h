@@ -96,13 +96,20 @@ inline std::vector<float> twiddle_half(int n) {
   return t;
 }
 
-// W512^m = exp(-2 pi i m / 512), m = 0..511, interleaved (re, im) as float.
+// W512^m = exp(-2 pi i m / 512), m = 0..511, interleaved (re, im) as float; behind them (entries
+// 512 .. 639) the untangle twiddles of the 16-lane transform in the form W512^k = c (1 - i t):
+// (t, c) = (tan, cos)(2 pi k / 512) for k = 0..127.
+constexpr int kTw512Entries = 512 + 128;
 inline std::vector<float> twiddle512() {
   const double pi = 3.14159265358979323846;
-  std::vector<float> t(1024);
+  std::vector<float> t(2 * kTw512Entries);
   for (int m = 0; m < 512; ++m) {
     t[2 * m] = (float)std::cos(2 * pi * m / 512.0);
     t[2 * m + 1] = (float)(-std::sin(2 * pi * m / 512.0));
+  }
+  for (int k = 0; k < 128; ++k) {
+    t[2 * (512 + k)] = (float)std::tan(2 * pi * k / 512.0);
+    t[2 * (512 + k) + 1] = (float)std::cos(2 * pi * k / 512.0);
   }
   return t;
 }

@@ -52,7 +52,8 @@ int main(int argc, char** argv) {
         mfcc::cf b = Z[pl][15 - s];
         if (q == 0) b = Z[0][(16 - s) & 15];
         float lo, hi;
-        mfcc::untangle_power(Z[q][s], b, mfcc::mk(tw[2 * k], tw[2 * k + 1]), lo, hi);
+        if ((trial & 1) == 0) mfcc::untangle_power_tc(Z[q][s], b, mfcc::mk(tw[2 * (512 + k)], tw[2 * (512 + k) + 1]), lo, hi);
+        else mfcc::untangle_power(Z[q][s], b, mfcc::mk(tw[2 * k], tw[2 * k + 1]), lo, hi);
         if (P[k] != -1.f || P[256 - k] != -1.f) { printf("bin written twice: %d\n", k); return 2; }
         P[k] = lo;
         P[256 - k] = hi;
