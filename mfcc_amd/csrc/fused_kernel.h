@@ -463,6 +463,54 @@ __device__ __forceinline__ void stage_load(const StageCtx<T>& c, StageRegs& r, i
     else r.prev[k] = (float)pv;
   }
 }
+// The same loads for the batches after a tile's first, through a buffer descriptor: its range check does
+// the work of the clamps (a chunk that starts behind the last chunk holding a byte of the buffer reads as
+// zeros instead of being pulled back; such samples lie outside the utterance and stage_store zeroes them
+// anyway), and nothing of these batches lies in front of the buffer, so the address of a load is a
+// per-lane offset that never changes plus wave-uniform scalars: no vector arithmetic per batch.
+// The descriptor is rebuilt per batch from scalars (base moved on by the batch's offset, the record count
+// shrunk by it), since the hardware leaves a scalar offset out of the range check.
+template <typename T>
+struct StageDesc {
+  const char* base16;  // 16 bytes in front of the tile's first aligned chunk
+  unsigned nrec;       // bytes from base16 to the end of the last chunk that holds a byte of the buffer
+  unsigned voff[sizeof(T) == 2 ? 2 : 3];  // per lane: byte offset of its chunks inside a batch
+};
+template <typename T, class G>
+__device__ __forceinline__ StageDesc<T> stage_desc(const StageCtx<T>& c, int tid) {
+  constexpr int NR = sizeof(T) == 2 ? 2 : 3;
+  StageDesc<T> d;
+  d.base16 = (const char*)c.base - 16;
+  d.nrec = (unsigned)c.hi_rel * (unsigned)sizeof(T) + 32u;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) d.voff[k] = min((unsigned)(tid + 256 * k), c.nchunk - 1) * 16u;
+  return d;
+}
+template <typename T, class G>
+__device__ __forceinline__ void stage_load_desc(StageDesc<T>& d, const StageCtx<T>& c, StageRegs& r, int batch_off) {
+  // batch_off = (first frame of the batch - first frame of the tile) * step, in elements, > 0
+  constexpr int NR = sizeof(T) == 2 ? 2 : 3;
+  constexpr unsigned SZ = (unsigned)sizeof(T);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  r.delta = c.delta;
+  const int boff = batch_off * (int)SZ;
+  // (signed scalar arithmetic: an unsigned saturating difference would be formed on the vector unit and make
+  // the descriptor a per-lane value; nrec < 2^31)
+  const int left = max((int)d.nrec - boff, 0);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<char*>(d.base16 + boff), 0, left, 0x00020000);
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    // (the offset passes through an empty asm statement, in its own register: the constants below then stay
+    // immediate offsets of the loads instead of being added into registers of their own in front of the loop)
+    asm volatile("" : "+v"(d.voff[k]));
+    const unsigned vo = d.voff[k];
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16u, 0, 0);
+    r.raw[k] = make_uint4(v.x, v.y, v.z, v.w);
+    if (sizeof(T) == 2) r.prev[k] = __builtin_bit_cast(float, (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo + (16u - SZ), 0, 0));
+    else r.prev[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo + (16u - SZ), 0, 0));
+  }
+}
+
 template <typename T, class G>
 __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int64_t len, int tb, int tid,
                                             float pre_hi, float pre_lo) {
@@ -633,6 +681,12 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   StageRegs sr;
   const StageCtx<T> sctx = stage_setup<T, G>((const T*)p.audio, p.total_elems, s_off, s_lo);
   auto stage_ld = [&](int tb) { stage_load<T, G>(sctx, sr, (tb - s_lo) * G::kStep, tid); };
+#ifdef MFCC_STAGE_CLAMPED
+  auto stage_ld_next = [&](int tb) { stage_load<T, G>(sctx, sr, (tb - s_lo) * G::kStep, tid); };
+#else
+  StageDesc<T> sdesc = stage_desc<T, G>(sctx, tid);
+  auto stage_ld_next = [&](int tb) { stage_load_desc<T, G>(sdesc, sctx, sr, (tb - s_lo) * G::kStep); };  // tb > s_lo
+#endif
   auto stage_st = [&](int tb) -> int {
     stage_store<T, G>(sr, abuf, len, tb, tid, pre_hi, pre_lo);
     return sr.delta;
@@ -820,7 +874,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     __builtin_amdgcn_s_setprio(MFCC_PRIO_FFT);
     // spectrum kinds have no filterbank phase to cover the staging loads of the next batch: they fly
     // during this batch's transforms instead
-    if (kSpecOut && !kStack) stage_ld(tb + kBatch);
+    if (kSpecOut && !kStack) stage_ld_next(tb + kBatch);
     f32x4 bv[kMelQuads];  // filter weights of this wave's slots (A operands), fetched at the end of the FFT section
     // ---- FFT-512 of 4 frames per wave, 16 lanes per frame -----------------------------
     {
@@ -977,9 +1031,20 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           pw[0] = mk(v0.x, v0.y); pw[1] = mk(v0.z, v0.w); pw[2] = mk(v1.x, v1.y); pw[3] = mk(v1.z, v1.w);
         }
         float lo4[4], hi4[4];  // MFCC kinds: the group's eight values, stored together below
+#ifndef MFCC_Q0_SELECT
+        // lane 0 pairs inside itself: Z[16 s] with Z[16 (16 - s)].  A real branch (the empty asm statement keeps it
+        // one): four 64-bit moves under the lane mask instead of eight selects in the three-operand encoding
+        if (q == 0) {
+          asm volatile("");
+#pragma unroll
+          for (int s = 0; s < 4; ++s) pb[s] = x[(16 - h - s) & 15];
+        }
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          if (q == 0) pb[s] = x[(16 - h - s) & 15];  // lane 0 pairs inside itself: Z[16 s] with Z[16 (16 - s)]
+#ifdef MFCC_Q0_SELECT
+          if (q == 0) pb[s] = x[(16 - h - s) & 15];
+#endif
           float lo, hi;
 #ifndef MFCC_ABL_UNT
           untangle_power_tc(x[h + s], pb[s], pw[s], lo, hi);
@@ -1034,7 +1099,11 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
           if (spec_row) spec_row[half_band ? 64 : 128] = spec_value(4.f * norm2(x[8]));
         } else {
           const float p128 = 4.f * norm2(x[8]);
-          const float v128 = mag ? __builtin_amdgcn_sqrtf(p128) : p128;
+          float v128 = p128;
+          if (mag) {  // a branch on the wave-uniform flag: the power path pays for neither the root nor a select
+            asm volatile("");
+            v128 = __builtin_amdgcn_sqrtf(p128);
+          }
           P[128] = v128;
           P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last k-steps
           esum.x += v128;
@@ -1043,7 +1112,10 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       if (!kSpecOut) {
         // sum over the frame's 16 lanes; a 256-point plan counts the even bins only (a lane's bins have the parity of q)
         float e = esum.x + esum.y;
-        if (half_band && (q & 1)) e = 0.f;
+        if (half_band) {  // wave-uniform: a branch, not two selects in every plan
+          asm volatile("");
+          if (q & 1) e = 0.f;
+        }
         e += row_ror<8>(e);
         e += row_ror<4>(e);
         e += row_ror<2>(e);
@@ -1052,7 +1124,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       }
     }
 #if !defined(MFCC_ABL_STAGE) && defined(MFCC_EARLY_STAGE)
-    stage_ld(tb + kBatch);
+    stage_ld_next(tb + kBatch);
     __builtin_amdgcn_sched_barrier(0);
 #endif
     MFCC_PHASE("5 barrier 1");
@@ -1071,7 +1143,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // whole 16-byte chunks inside it come straight from the source row (aligned in LDS by its
       // phase); the chunk that straddles two blocks (or two rows) is put together from single floats
       // by one lane.  Only the first and last chunk of an utterance are partial.
-      stage_ld(tb + kBatch);
+      stage_ld_next(tb + kBatch);
       constexpr int B = kNbin;
       const int N = p.stack_n, hN = N >> 1;
       const int64_t W = (int64_t)N * B;
@@ -1205,7 +1277,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
     // ---- mel filterbank on the matrix cores: D[frame][col] = sum_bin P[frame][bin] W[bin][col]
 #if !defined(MFCC_ABL_STAGE) && !defined(MFCC_EARLY_STAGE)
     MFCC_PHASE("6 next batch's global loads, filterbank operand reads");
-    stage_ld(tb + kBatch);  // unconditional and branch-free; HBM latency runs under the MFMAs below
+    stage_ld_next(tb + kBatch);  // unconditional and branch-free; HBM latency runs under the MFMAs below
     __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the matrix-core chain
 #endif
     {
