@@ -710,6 +710,11 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   // reference pads twice -- delta-delta is the regression over the edge-padded DELTA sequence --
   // so a delta tap that falls outside the utterance takes the delta of the edge row, not the
   // regression over a shifted window.
+  const unsigned row_lane_off = (unsigned)(g4 * ld + q);  // a lane's element inside its wave's four output rows
+  // LDS address of the lane's column in ring row 0, opaque to the compiler: the ring's offset inside the carve
+  // then stays part of this register instead of being added to every row address again
+  unsigned ring_q_addr = lds_addr(ring + q);
+  asm volatile("" : "+v"(ring_q_addr));
   auto emit_rows = [&](int r_first) {
     const int r = r_first + 4 * wave + g4;
     const int r_wave = r_first + 4 * wave;  // wave-uniform
@@ -719,13 +724,27 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // two regressions per packed instruction: the rows are read once as the pairs (v0,v1) .. (v6,v7)
       // and once more as (v1,v2) .. (v7,v8); same operations in the same order as regress()
       const int b0 = r - kHalo - s_lo + 8;
-      const float* const w0 = ring + (b0 & 31) * RP + q;
+      typedef const float __attribute__((address_space(3))) * lfloat_ptr;
+      const lfloat_ptr w0 = (lfloat_ptr)(uintptr_t)(ring_q_addr + (unsigned)((b0 & 31) * (RP * 4)));
       auto at = [&](int m) { return kMirror ? w0[m * RP] : ring[((b0 + m) & 31) * RP + q]; };
       cf pe[4], po[4];
+      if (kMirror) {
+        // the odd pairs are read once more from LDS (through a pointer the compiler cannot tell from w0 + RP)
+        // rather than put together from the even pairs' registers with six moves: the reads cost no vector issue
+        int one_row = RP;
+        asm volatile("" : "+s"(one_row));
+        const lfloat_ptr w1 = w0 + one_row;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        pe[m] = mk(at(2 * m), at(2 * m + 1));
-        po[m] = mk(at(2 * m + 1), at(2 * m + 2));
+        for (int m = 0; m < 4; ++m) {
+          pe[m] = mk(w0[2 * m * RP], w0[(2 * m + 1) * RP]);
+          po[m] = mk(w1[2 * m * RP], w1[(2 * m + 1) * RP]);
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          pe[m] = mk(at(2 * m), at(2 * m + 1));
+          po[m] = mk(at(2 * m + 1), at(2 * m + 2));
+        }
       }
       const cf two = mk(2.f, 2.f), zero = mk(0.f, 0.f), tenth = mk(0.1f, 0.1f);
       auto regress2 = [&](cf a, cf b, cf m, cf dd, cf e) {
@@ -778,7 +797,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       const float dd = regress(d[0], d[1], d[2], d[3], d[4]);
       const bool in = r >= t0 && r < t0 + nt;
       if (q < ncep && in) {
-        float* const o = out_t0 + (r - t0) * ld + q;
+        float* const o = out_t0 + (int64_t)(r_wave - t0) * ld + row_lane_off;  // wave-uniform row + the lane's fixed offset
         o[0] = v[4];
         o[ncep] = d[2];
         o[2 * ncep] = dd;
@@ -808,7 +827,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
         if (!(lane & 16)) cs[64 + 16 * (lane >> 5) + q] += r2;
       }
     } else if (q < ncep && r >= t0 && r < t0 + nt) {
-      float* const o = out_t0 + (r - t0) * ld + q;
+      float* const o = out_t0 + (int64_t)(r_wave - t0) * ld + row_lane_off;  // wave-uniform row + the lane's fixed offset
       o[0] = v[4];
       o[ncep] = d[2];
       o[2 * ncep] = regress(d[0], d[1], d[2], d[3], d[4]);
