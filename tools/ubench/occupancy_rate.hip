@@ -30,6 +30,17 @@ __global__ void k(float* out, int iters, float seed) {
       if (KIND == 7) asm volatile("v_mov_b64 %0, %1" : "=v"(d[i]) : "v"(dc));
       if (KIND == 8) asm volatile("v_pk_fma_f16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(c));
       if (KIND == 9) asm volatile("v_pk_mov_b32 %0, %1, %1" : "=v"(b[i]) : "v"(c2));
+      // source operand count of a packed fma: three different register pairs; two pairs and a scalar pair; the
+      // modifiers of a complex product's second half; a chain in which every instruction needs the one before it
+      if (KIND == 12) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(b[(i + 5) & 15]), "v"(c2));
+      if (KIND == 13) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(b[i]) : "s"(c2), "v"(b[(i + 5) & 15]));
+      if (KIND == 14) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(b[i]) : "v"(b[(i + 5) & 15]), "v"(c2));
+      if (KIND == 15) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(b[(i + 1) & 15]) : "v"(b[i]), "v"(c2));
+      if (KIND == 16) asm volatile("v_pk_add_f32 %0, %1, %2" : "+v"(b[i]) : "v"(b[(i + 5) & 15]), "v"(b[(i + 9) & 15]));
+      if (KIND == 17) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(b[i]) : "v"(b[(i + 5) & 15]));     // result over its first source
+      if (KIND == 18) asm volatile("v_pk_add_f32 %0, %1, %2" : "+v"(b[i]) : "v"(b[(i + 5) & 15]), "v"(c2));  // one source shared by all
+      if (KIND == 19) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "+v"(b[i]) : "v"(b[(i + 5) & 15]), "s"(c2), "v"(b[(i + 9) & 15]));
+      if (KIND == 20) asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(b[i]) : "v"(b[(i + 5) & 15]), "v"(b[(i + 9) & 15]));
       if (KIND == 10) {  // the transform's mix: packed and plain alternate
         if (i & 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(b[i]) : "v"(c2));
         else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
@@ -88,6 +99,15 @@ int main() {
   run<7>("v_mov_b64");
   run<9>("v_pk_mov_b32");
   run<8>("v_pk_fma_f16");
+  run<12>("pk_fma 3 vgpr");
+  run<13>("pk_fma 2v+s");
+  run<14>("pk_fma 3v mod");
+  run<15>("pk_fma chain");
+  run<16>("pk_add 2 src");
+  run<17>("pk_add d=s0");
+  run<18>("pk_add shared");
+  run<19>("pk_fma v,s,v");
+  run<20>("pk_mul 2 src");
   run<10>("pk/plain 1:1");
   run<11>("pk/plain 3:1");
   return 0;
