@@ -546,6 +546,7 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int
     // by a two-term coefficient and fused multiply-adds, two samples per packed instruction;
     // float32 input: numpy works in float32 with two roundings.
     if (sizeof(T) == 2) {
+#ifdef MFCC_STAGE_PACKED
       const cf nhi = mk(-pre_hi, -pre_hi), nlo = mk(-pre_lo, -pre_lo);
 #pragma unroll
       for (int j = 0; j < CE; j += 2) {
@@ -554,6 +555,12 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, float* abuf, int
         y[j] = r.x;
         y[j + 1] = r.y;
       }
+#else
+      // (plain fmas: the packed form needs the shifted pairs (x[j], x[j+1]) and (x[j+1], x[j+2]) put together with
+      // a move per sample, and a packed fma costs more issue time than two plain ones save)
+#pragma unroll
+      for (int j = 0; j < CE; ++j) y[j] = __builtin_fmaf(-pre_lo, x[j], __builtin_fmaf(-pre_hi, x[j], x[j + 1]));
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < CE; ++j) y[j] = __fsub_rn(x[j + 1], __fmul_rn(pre_hi, x[j]));
