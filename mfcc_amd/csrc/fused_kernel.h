@@ -496,14 +496,22 @@ __device__ __forceinline__ void stage_load_desc(StageDesc<T>& d, const StageCtx<
   const int boff = batch_off * (int)SZ;
   // (signed scalar arithmetic: an unsigned saturating difference would be formed on the vector unit and make
   // the descriptor a per-lane value; nrec < 2^31)
-  const int left = max((int)d.nrec - boff, 0);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<char*>(d.base16 + boff), 0, left, 0x00020000);
+  constexpr int CE = 16 / (int)sizeof(T);
+  constexpr int kMinChunks = (G::kStageLen + CE - 1) / CE;  // chunks of a batch at least
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
+    // A round of chunks that every batch has in full (the second of three with float32 samples) needs no offset
+    // register of its own: its chunks lie 4096 k bytes behind the first round's, and the descriptor moves instead.
+    const bool derived = k > 0 && 256 * (k + 1) <= kMinChunks;
+    const int shift = derived ? 4096 * k : 0;
+    const int left = max((int)d.nrec - boff - shift, 0);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<char*>(d.base16 + boff + shift), 0, left, 0x00020000);
     // (the offset passes through an empty asm statement, in its own register: the constants below then stay
     // immediate offsets of the loads instead of being added into registers of their own in front of the loop)
-    asm volatile("" : "+v"(d.voff[k]));
-    const unsigned vo = d.voff[k];
+    unsigned& vreg = d.voff[derived ? 0 : k];
+    asm volatile("" : "+v"(vreg));
+    const unsigned vo = vreg;
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16u, 0, 0);
     r.raw[k] = make_uint4(v.x, v.y, v.z, v.w);
     if (sizeof(T) == 2) r.prev[k] = __builtin_bit_cast(float, (int)(short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo + (16u - SZ), 0, 0));
