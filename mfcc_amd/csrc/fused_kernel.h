@@ -1041,6 +1041,7 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // those of the second on an 8-byte boundary (rows with odd t sit two floats off).
       float* const P = kStack ? sring + ((tb + fb - s_lo) & srow_mask) * kSRingPitch + (int)((stack_sign * f_off + tb + fb + (p.stack_n >> 1)) & 3)
                               : xbuf + fb * 512 + row_skew(fb);
+      float* const Phi = P + (256 - 16 * 7) - q;  // the lane's upper bins 256 - q - 16 s, lowest address first
       // spectrum kinds: output row of this lane group's frame (nullptr past the tile's last frame)
       float* const spec_row = (kSpecOut && !kStack && tb + fb < s_hi) ? out_t0 + (tb + fb - t0) * ld : nullptr;
       auto spec_value = [&](float p4) {
@@ -1119,11 +1120,11 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
             }
           }
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            P[q + 16 * (h + s)] = lo4[s];
-            P[256 - q - 16 * (h + s)] = hi4[s];
-            esum = esum + mk(lo4[s], hi4[s]);
-          }
+          for (int s = 0; s < 4; ++s) P[q + 16 * (h + s)] = lo4[s];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) Phi[16 * (7 - (h + s))] = hi4[s];  // = P[256 - q - 16 (h + s)]: one base register and offsets
+#pragma unroll
+          for (int s = 0; s < 4; ++s) esum = esum + mk(lo4[s], hi4[s]);
         }
       }
       if (q == 0) {  // bin 128 pairs with itself: X[128] = conj Z[128]
@@ -1139,7 +1140,8 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
             v128 = __builtin_amdgcn_sqrtf(p128);
           }
           P[128] = v128;
-          P[257] = 0.f; P[258] = 0.f; P[259] = 0.f;  // read (with zero weight) by the last k-steps
+          // (P[257..259], read with zero weights by the last k-steps, keep what this frame's transform left in its
+          // exchange slot: finite whenever the frame is, and a frame that is not has no finite filter sum anyway)
           esum.x += v128;
         }
       }
