@@ -376,6 +376,12 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
+// v of lane (16 - q) & 15 of the caller's row of 16 lanes, q = its own index in the row, by two data-parallel moves on the
+// vector ALU: rotate the row left by one lane (row_ror:15), then mirror it
+__device__ __forceinline__ float partner_dpp(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + 15, 0xf, 0xf, true);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, r, 0x140 /* row_mirror */, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float lane_read(int byte_addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
@@ -691,7 +697,9 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   if (kSums)
     for (int i = tid; i < kSumsLdsFloats; i += 256) csum[i] = 0.f;
   const cf* const twq = (const cf*)(twl + q * kTwPitch);
+#ifdef MFCC_PARTNER_BPERMUTE
   const int partner_addr = ((lane & 48) | partner_lane(q)) << 2;
+#endif
 
   StageRegs sr;
   const StageCtx<T> sctx = stage_setup<T, G>((const T*)p.audio, p.total_elems, s_off, s_lo);
@@ -1053,13 +1061,18 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
       // the frame's energy sum (mfcc-self5.py:130) is collected on the way: every bin passes through
       // exactly one lane of the frame here
       cf esum = mk(0.f, 0.f);
-      // Z[256-k] lives in the partner lane: fetch four partners and four untangle twiddles at
-      // a time, so that their latencies overlap instead of adding up
+      // Z[256-k] lives in the partner lane (16 - q) & 15 of the frame's row of lanes: four partners and four untangle
+      // twiddles at a time
 #pragma unroll
       for (int h = 0; h < 8; h += 4) {
         cf pb[4], pw[4];
 #pragma unroll
+#ifndef MFCC_PARTNER_BPERMUTE
+        // (two vector moves per value instead of a ds_bpermute: the LDS path is the scarcer resource, 0.970 -> 0.952 ms)
+        for (int s = 0; s < 4; ++s) pb[s] = mk(partner_dpp(x[15 - h - s].x), partner_dpp(x[15 - h - s].y));
+#else
         for (int s = 0; s < 4; ++s) pb[s] = mk(lane_read(partner_addr, x[15 - h - s].x), lane_read(partner_addr, x[15 - h - s].y));
+#endif
         {
           const float4* const tv = (const float4*)__builtin_assume_aligned(twq + kTwUnt + h, 16);
           const float4 v0 = tv[0], v1 = tv[1];

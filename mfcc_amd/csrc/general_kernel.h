@@ -167,7 +167,6 @@ __global__ void __launch_bounds__(256, 3) general16_kernel(const FusedParams p, 
   for (int i = tid; i < gc.dct_lds; i += 256) tables[gc.bankc_lds + i] = i < nmel * ncep ? gc.dctl[i] : 0.f;
   for (int i = tid; i < 3 * nmel; i += 256) bandl[i] = gc.band[i];
   __syncthreads();
-  const int partner_addr = ((lane & 48) | partner_lane(q_lane)) << 2;
 
   for (int tq = s_lo + 4 * wave; tq < s_hi; tq += 16) {
     // The lane's index inside its frame passes through an empty asm statement: everything derived from it below
@@ -238,7 +237,7 @@ __global__ void __launch_bounds__(256, 3) general16_kernel(const FusedParams p, 
     };
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      cf pb = mk(lane_read(partner_addr, xr[15 - s].x), lane_read(partner_addr, xr[15 - s].y));
+      cf pb = mk(partner_dpp(xr[15 - s].x), partner_dpp(xr[15 - s].y));  // Z[256 - k] sits in lane (16 - q) & 15 of the frame's row
       if (q == 0) pb = xr[(16 - s) & 15];  // lane 0 pairs inside itself
       float lo, hi2;
       untangle_power(xr[s], pb, twl[q + 16 * s], lo, hi2);
