@@ -678,6 +678,12 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   typedef const f32x4 __attribute__((address_space(1))) * gfloat4_ptr;
   const gfloat4_ptr melW4 = (gfloat4_ptr)(uintptr_t)pc->melW + (wave * kMelQuads) * 16 + (lane & 15);
 
+  // The first batch's samples are requested before the tables below are copied: their way from HBM is the longest
+  // wait of a tile's set-up, and the table copies (L2 hits) run inside it.
+  StageRegs sr;
+  const StageCtx<T> sctx = stage_setup<T, G>((const T*)p.audio, p.total_elems, s_off, s_lo);
+  stage_load<T, G>(sctx, sr, 0, tid);
+
   // Twiddles per lane index q: stage 1 uses W256^(q k1) = W512^(2 q k1), k1 = 1..15, the
   // untangle W512^(q + 16 s), s = 0..7, as (tan, cos) pairs.  They live in LDS (row q, 23 pairs) and are
   // read when needed: 46 registers per lane would cost a wave of occupancy.
@@ -701,9 +707,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   const int partner_addr = ((lane & 48) | partner_lane(q)) << 2;
 #endif
 
-  StageRegs sr;
-  const StageCtx<T> sctx = stage_setup<T, G>((const T*)p.audio, p.total_elems, s_off, s_lo);
-  auto stage_ld = [&](int tb) { stage_load<T, G>(sctx, sr, (tb - s_lo) * G::kStep, tid); };
 #ifdef MFCC_STAGE_CLAMPED
   auto stage_ld_next = [&](int tb) { stage_load<T, G>(sctx, sr, (tb - s_lo) * G::kStep, tid); };
 #else
@@ -717,7 +720,6 @@ __global__ void __launch_bounds__(256, MFCC_MIN_WAVES) fused_kernel(const FusedP
   // floor of the mel energies: 0 = none (ln 0 = -inf as the reference, mfcc-self5.py:125-127)
   const bool floor_mel = pc->floor_mel != 0;
 
-  stage_ld(s_lo);
   int delta = stage_st(s_lo);
   __syncthreads();
 
