@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""What a tile costs beyond its batches: the MFCC-39 kernel on batches of equal total length cut into utterances of
+3 s, 1.5 s, 6 s and 0.75 s (19, 10, 19 + halo and 5 batches per tile).  T = tiles * S + batches * B gives S and B.
+
+    python3 tools/setup_cost.py
+"""
 import sys, os, torch
 sys.path.insert(0, '.')
 import mfcc_amd.frontend as F
