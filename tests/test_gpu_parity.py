@@ -777,3 +777,35 @@ def test_streaming_large_chunks_span_several_tiles():
     off = mfcc_amd.MFCC("self5")(torch.from_numpy(audio).cuda()).cpu().numpy().reshape(2, -1, 39)
     assert got.shape == off.shape
     np.testing.assert_allclose(got, off, rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
+def test_views_into_larger_buffers_ignore_what_lies_around_them(dtype):
+    """The staging loads fetch aligned 16-byte chunks, clamped (a tile's first batch) or range-checked by a buffer
+    descriptor (the later ones), so they touch bytes in front of and behind the samples they were given.  The
+    same samples at element offsets 0, 1, 3, 5 and 8 of a larger tensor whose other elements are NaN (float32) or
+    full-scale noise (int16) must give the same bits as a tensor of their own: nothing outside the view counts,
+    whatever 16-byte phase and sample parity the view starts on."""
+    import mfcc_amd
+    rng = np.random.default_rng(77)
+    lengths = [1, 399, 401, 2959, 48000, 52345, 7, 16001, 97000]
+    n = sum(lengths)
+    host = rng.standard_normal(n) * 3000
+    if dtype == torch.int16:
+        own = torch.from_numpy(np.clip(host, -32768, 32767).astype(np.int16)).cuda()
+    else:
+        own = torch.from_numpy((host / 32768).astype(np.float32)).cuda()
+    fe = mfcc_amd.MFCC("self5")
+    lay = fe.layout(lengths)
+    ref = fe.forward(own, lay, kind="mfcc39").clone()
+    assert torch.isfinite(ref).all()
+    for off in (0, 1, 3, 5, 8):
+        big = torch.empty(n + 4096 + off, dtype=dtype, device="cuda")
+        if dtype == torch.int16:
+            big[:] = torch.from_numpy(rng.choice(np.array([-32768, 32767], dtype=np.int16), size=big.numel())).cuda()
+        else:
+            big[:] = float("nan")
+        big[off:off + n] = own
+        out = fe.forward(big[off:off + n], lay, kind="mfcc39")
+        assert torch.equal(out, ref), f"{dtype}, view at element {off}: rows differ from those of a tensor of its own"
